@@ -1,0 +1,103 @@
+"""Oracle (test infrastructure): Philox4x32-10 and the draw rules of the HIP sampling kernels.
+
+Philox4x32-10 follows the published algorithm (Salmon et al., "Parallel random numbers: as easy
+as 1, 2, 3", SC'11; constants M0=0xD2511F53, M1=0xCD9E8D57, W0=0x9E3779B9, W1=0xBB67AE85).  The
+reference has no counter-based RNG (it uses the global torch generator); this file
+restates the *build's* device RNG so GPU draws can be replayed bit-exactly on the CPU.
+
+Counter layout used by every kernel (csrc/philox.hpp):
+    counter = (row_lo, row_hi, offset, draw)   key = (seed_lo, seed_hi)
+where row = flat row index (n*D+d, or b for per-batch draws), offset = host-supplied call index
+(sampler step / corrector sub-step), draw = 0,1,2,... successive 4-word blocks for that row.
+"""
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = np.uint32(0x9E3779B9)
+W1 = np.uint32(0xBB67AE85)
+MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """All args broadcastable uint32 arrays.  Returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint32).astype(np.uint64) for c in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = M0 * c0
+            p1 = M1 * c2
+            hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
+            hi1, lo1 = p1 >> np.uint64(32), p1 & MASK32
+            n0 = hi1 ^ c1 ^ np.uint64(k0)
+            n1 = lo1
+            n2 = hi0 ^ c3 ^ np.uint64(k1)
+            n3 = lo0
+            c0, c1, c2, c3 = n0, n1, n2, n3
+            k0 = np.uint32((int(k0) + int(W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(W1)) & 0xFFFFFFFF)
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def u01(r):
+    """uint32 -> float32 in the open interval (0,1): (r>>8)*2^-24 + 2^-25 (exact in fp32)."""
+    return ((r >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float32)
+
+
+def exp1(r):
+    """uint32 -> Exp(1) float32: -log(u01(r))."""
+    return (-np.log(u01(r).astype(np.float32))).astype(np.float32)
+
+
+def row_uniforms(rows, offset, seed, ndraw_blocks=1):
+    """uniforms[row, 4*ndraw_blocks] for flat row ids `rows` (uint64-able)."""
+    rows = np.asarray(rows, dtype=np.uint64)
+    lo = (rows & MASK32).astype(np.uint32)
+    hi = (rows >> np.uint64(32)).astype(np.uint32)
+    k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    out = []
+    for j in range(ndraw_blocks):
+        r = philox4x32_10(lo, hi, np.uint32(offset), np.uint32(j), k0, k1)
+        out.extend(u01(x) for x in r)
+    return np.stack(out, axis=-1)
+
+
+# ------------------------------------------------------------------ draw rules of the kernels
+POISSON_ICDF_MAX_LAMBDA = 12.0   # rows with total rate*h above this take the per-element path
+POISSON_ICDF_KMAX = 64
+
+
+def poisson_icdf(lam, u):
+    """Sequential-search inverse CDF, float32 arithmetic, same operation order as the kernel:
+    k=0; p=exp(-lam); c=p; while (u > c && k < KMAX) { k++; p = p*lam/k; c += p; }"""
+    lam = np.asarray(lam, dtype=np.float32)
+    u = np.asarray(u, dtype=np.float32)
+    k = np.zeros(lam.shape, dtype=np.int32)
+    p = np.exp(-lam).astype(np.float32)
+    c = p.copy()
+    margin = np.abs(u - c)                       # distance to the nearest tested boundary
+    active = u > c
+    it = 0
+    while active.any() and it < POISSON_ICDF_KMAX:
+        it += 1
+        k = np.where(active, k + 1, k)
+        p = np.where(active, (p * lam / k.clip(1).astype(np.float32)).astype(np.float32), p)
+        c = np.where(active, (c + p).astype(np.float32), c)
+        margin = np.where(active, np.minimum(margin, np.abs(u - c)), margin)
+        active = active & (u > c)
+    return k, margin
+
+
+def categorical_icdf(w, u):
+    """First index s with cumsum(w)[s] > u*sum(w) (w >= 0, float32, row-wise).
+    Returns (index, margin) where margin is the relative distance of the target to the nearest
+    cumulative boundary -- tests skip rows whose margin is below fp32 reassociation noise."""
+    w = np.asarray(w, dtype=np.float64)
+    cs = np.cumsum(w, axis=-1)
+    tot = cs[..., -1:]
+    target = np.asarray(u, dtype=np.float64)[..., None] * tot
+    idx = np.sum(cs <= target, axis=-1)
+    idx = np.minimum(idx, w.shape[-1] - 1)
+    margin = np.min(np.abs(cs - target), axis=-1) / np.maximum(tot[..., 0], 1e-300)
+    return idx.astype(np.int64), margin
