@@ -1,0 +1,496 @@
+// steps_generic.hip -- reverse rates, SDDM log-probs and the sampler step kernels for ANY S.
+//
+// Layout: a row = one (n,d) pair = S contiguous fp32 logits.  G = min(64, pow2ceil(S)) lanes
+// of a wave own one row (element s = li + k*G, k < EPT), so every row reduction is an
+// in-wave xor-shuffle over masks < G and small-S problems (maze S=3, synthetic S=2) pack
+// 16-32 rows per wave.  The S x S contraction broadcasts w[s0] by shuffle and reads the
+// q_{t|0} table through L1/L2.  This is the correctness-first path for every S; S = 256 (MNIST,
+// CIFAR) is overridden by the LDS/MFMA-tiled kernel in steps_s256.hip.
+//
+// Reference semantics: lib/sampling/sampling.py:31-78 (rates), 119-160 (tau-leap), 278-293
+// (LBJF), 417-453 (midpoint); lib/models/model_utils.py:30-60 (log-probs).
+#include "draw.hpp"
+
+namespace ctdd {
+
+enum Mode { MODE_RATES = 0, MODE_LOGPROB = 1, MODE_TAULEAP = 2, MODE_LBJF = 3, MODE_MIDPOINT = 4,
+            MODE_DRAW_ONLY = 5 };
+
+struct StepArgs {
+  const float* logits;   // (N,D,S)   [MODE_DRAW_ONLY: the rates themselves]
+  const int32_t* x;      // (N,D)
+  const int32_t* x_base; // (N,D) or null
+  const float* qt0;      // (nT,S,S) or null (direct)
+  const float* rate;     // (nT,S,S) table, or (S,S) base rate scaled by beta
+  const int32_t* tidx;   // (N) or null
+  const float* E;        // (N*D,S) explicit exponential noise or null
+  float beta, eps, h;
+  uint32_t flags;
+  uint64_t seed, offset;
+  int N, D, S, G;
+  int branch, logit_type, mode;
+  float* out_a;          // rates | ll_all | probs
+  float* out_b;          // ratio | ll_xt
+  int32_t* out_x;
+  int32_t* out_changed;
+};
+
+__device__ inline float grp_sum(float v, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+__device__ inline int grp_sum_i(int v, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+__device__ inline float grp_max(float v, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, WAVE));
+  return v;
+}
+// (value, index) arg-max with first-index tie-break (torch.argmax)
+__device__ inline void grp_argmax(float& v, int& i, int G) {
+  for (int m = G >> 1; m >= 1; m >>= 1) {
+    const float ov = __shfl_xor(v, m, WAVE);
+    const int oi = __shfl_xor(i, m, WAVE);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+template <int EPT>
+__global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = a.G, S = a.S;
+  const int li = lane & (G - 1), gi = lane / G, gbase = lane - li;
+  const int64_t R = (int64_t)a.N * a.D;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * (WAVE / G) + gi;
+  const bool live = row < R;
+  const int64_t rowc = live ? row : R - 1;
+  const int n = (int)(rowc / a.D);
+  const int tbl = a.tidx ? a.tidx[n] : 0;
+  const float* qt0 = a.qt0 ? a.qt0 + (size_t)tbl * S * S : nullptr;
+  const float* rate = a.rate ? a.rate + (size_t)tbl * S * S : nullptr;
+  int xv = a.x[rowc];
+  xv = min(max(xv, 0), S - 1);
+  const float* lrow = a.logits + (size_t)rowc * S;
+
+  float rr[EPT];     // reverse rates (own state NOT zeroed)
+  float ratio[EPT];
+
+  if (a.mode == MODE_DRAW_ONLY) {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      rr[k] = s < S ? lrow[s] : 0.0f;
+      ratio[k] = 0.0f;
+    }
+  } else {
+    // ---- softmax pieces
+    float l[EPT], e[EPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      l[k] = s < S ? lrow[s] : -INFINITY;
+      m = fmaxf(m, l[k]);
+    }
+    m = grp_max(m, G);
+    float z = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      e[k] = s < S ? expf(l[k] - m) : 0.0f;
+      z += e[k];
+    }
+    z = grp_sum(z, G);
+
+    if (a.branch == CTDD_BRANCH_CTELBO && a.mode != MODE_LOGPROB) {
+      // w[s0] = softmax[s0] / (qt0[s0][x] + eps);  ratio[s] = sum_s0 w[s0] qt0[s0][s]
+      float w[EPT];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int s = li + k * G;
+        w[k] = s < S ? (e[k] / z) / (qt0[(size_t)s * S + xv] + a.eps) : 0.0f;
+        ratio[k] = 0.0f;
+      }
+#pragma unroll
+      for (int k0 = 0; k0 < EPT; ++k0) {
+        for (int j = 0; j < G; ++j) {
+          const int s0 = j + k0 * G;
+          if (s0 >= S) break;
+          const float ws = __shfl(w[k0], gbase + j, WAVE);
+          const float* qrow = qt0 + (size_t)s0 * S;
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            const int s = li + k * G;
+            if (s < S) ratio[k] = fmaf(ws, qrow[s], ratio[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int s = li + k * G;
+        const float fwd = s < S ? a.beta * rate[(size_t)s * S + xv] : 0.0f;   // rate[s][x]
+        rr[k] = fwd * ratio[k];
+      }
+    } else {
+      // ---- SDDM branch: ll_all by logit_type, ratio = exp(ll_all - ll_xt), R^ = ratio * rate[x][s]
+      float ll[EPT];
+      const float logz = logf(z);
+      if (a.logit_type == CTDD_LOGIT_DIRECT) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) ll[k] = l[k] - m - logz;
+      } else if (a.logit_type == CTDD_LOGIT_REVERSE_PROB) {
+        float acc[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) acc[k] = 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < EPT; ++k0) {
+          for (int j = 0; j < G; ++j) {
+            const int s0 = j + k0 * G;
+            if (s0 >= S) break;
+            const float ps = __shfl(e[k0] / z, gbase + j, WAVE);
+            const float* qrow = qt0 + (size_t)s0 * S;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+              const int s = li + k * G;
+              if (s < S) acc[k] = fmaf(ps, qrow[s], acc[k]);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) ll[k] = logf(acc[k] + 1e-35f);
+      } else {  // reverse_logscale: logsumexp_s0(log_p0t[s0] + log qt0[s0][s])
+        float mx[EPT], sm[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { mx[k] = -INFINITY; sm[k] = 0.0f; }
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+          for (int k0 = 0; k0 < EPT; ++k0) {
+            for (int j = 0; j < G; ++j) {
+              const int s0 = j + k0 * G;
+              if (s0 >= S) break;
+              const float lp = __shfl(l[k0] - m - logz, gbase + j, WAVE);
+              const float* qrow = qt0 + (size_t)s0 * S;
+#pragma unroll
+              for (int k = 0; k < EPT; ++k) {
+                const int s = li + k * G;
+                if (s < S) {
+                  const float q = qrow[s];
+                  const float t = lp + (q <= 1e-35f ? -1e9f : logf(q));
+                  if (pass == 0) mx[k] = fmaxf(mx[k], t);
+                  else sm[k] += expf(t - mx[k]);
+                }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) ll[k] = mx[k] + logf(sm[k]);
+      }
+      // ll_xt = ll_all at the current state
+      float sel = 0.0f;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) sel = (k == xv / G) ? ll[k] : sel;
+      const float ll_xt = __shfl(sel, gbase + (xv & (G - 1)), WAVE);
+      if (a.mode == MODE_LOGPROB) {
+        if (live) {
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            const int s = li + k * G;
+            if (s < S) a.out_a[(size_t)row * S + s] = ll[k];
+          }
+          if (li == 0) a.out_b[row] = ll_xt;
+        }
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int s = li + k * G;
+        ratio[k] = expf(ll[k] - ll_xt);
+        const float fwd = s < S ? a.beta * rate[(size_t)xv * S + s] : 0.0f;   // rate[x][s]
+        rr[k] = s < S ? ratio[k] * fwd : 0.0f;
+      }
+    }
+  }
+
+  if (a.mode == MODE_RATES) {
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int s = li + k * G;
+        if (s < S) {
+          a.out_a[(size_t)row * S + s] = rr[k];
+          if (a.out_b) a.out_b[(size_t)row * S + s] = ratio[k];
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- mask the own state (sampling.py:127-128); corrector adds the x -> s forward rate first
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int s = li + k * G;
+    if ((a.flags & CTDD_STEP_CORRECTOR) && s < S) rr[k] += a.beta * rate[(size_t)xv * S + s];
+    if (s == xv || s >= S) rr[k] = 0.0f;
+  }
+  const int base = a.x_base ? min(max(a.x_base[rowc], 0), S - 1) : xv;
+
+  if (a.mode == MODE_MIDPOINT) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) acc += rr[k] * (float)(li + k * G - xv);
+    acc = grp_sum(acc, G);
+    const int change = (int)rintf(a.h * acc);   // a.h carries float(0.5*h)
+    if (live && li == 0) a.out_x[row] = min(max(xv + change, 0), S - 1);
+    return;
+  }
+
+  if (a.mode == MODE_LBJF) {
+    // P = h*R^ + clip(1 - h*sum, 0) at own state; normalise; Categorical(logits = log(P + 1e-35))
+    float off = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) off += rr[k];
+    off = grp_sum(off, G);
+    const float diag = fmaxf(1.0f - a.h * off, 0.0f);
+    float P[EPT], tot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      P[k] = s < S ? (s == xv ? diag : rr[k] * a.h) : 0.0f;
+      tot += P[k];
+    }
+    tot = grp_sum(tot, G);
+    float lg[EPT], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      lg[k] = s < S ? logf(P[k] / tot + 1e-35f) : -INFINITY;
+      mx = fmaxf(mx, lg[k]);
+    }
+    mx = grp_max(mx, G);
+    float se = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) se += (li + k * G < S) ? expf(lg[k] - mx) : 0.0f;
+    se = grp_sum(se, G);
+    const float lse = mx + logf(se);
+    // probs = softmax(lg - lse)
+    float pr[EPT], mx2 = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { lg[k] -= lse; mx2 = fmaxf(mx2, lg[k]); }
+    mx2 = grp_max(mx2, G);
+    float se2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { pr[k] = (li + k * G < S) ? expf(lg[k] - mx2) : 0.0f; se2 += pr[k]; }
+    se2 = grp_sum(se2, G);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      if (s < S) {
+        pr[k] /= se2;
+        if (live && a.out_a) a.out_a[(size_t)row * S + s] = pr[k];
+        float Ev;
+        if (a.E) Ev = a.E[(size_t)rowc * S + s];
+        else Ev = -logf(u01(philox_row(a.seed, a.offset, (uint64_t)rowc, (uint32_t)s).x));
+        const float v = pr[k] / Ev;
+        if (v > best || (v == best && s < bi)) { best = v; bi = s; }
+      }
+    }
+    grp_argmax(best, bi, G);
+    if (live && li == 0) {
+      a.out_x[row] = bi;
+      if (a.out_changed && bi != xv) atomicAdd(a.out_changed, 1);
+    }
+    return;
+  }
+
+  // ---- MODE_TAULEAP / MODE_DRAW_ONLY: K ~ Poisson(h * sum rr), K destinations ~ Categorical(rr)
+  float T = 0.0f;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) T += rr[k];
+  T = grp_sum(T, G);
+  const float Lam = T * a.h;
+  const bool ordinal = a.flags & CTDD_STEP_ORDINAL;
+  int jump = 0;
+  if (Lam > 0.0f && Lam <= POISSON_ICDF_MAX_LAMBDA) {
+    PhiloxStream rng(a.seed, a.offset, (uint64_t)rowc, 0u);   // identical in every lane of the row
+    const int K = poisson_icdf(Lam, rng.next());
+    if (K > 0 && (ordinal || K == 1)) {
+      // inclusive prefix sums of rr in s order (s = li + k*G)
+      float c[EPT], carry = 0.0f;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        float v = rr[k];
+        for (int d = 1; d < G; d <<= 1) {
+          const float t = __shfl_up(v, d, WAVE);
+          if (li >= d) v += t;
+        }
+        c[k] = v + carry;
+        carry = __shfl(c[k], gbase + G - 1, WAVE);
+      }
+      for (int j = 0; j < K; ++j) {
+        const float target = rng.next() * T;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) cnt += (li + k * G < S && c[k] <= target) ? 1 : 0;
+        cnt = grp_sum_i(cnt, G);
+        jump += min(cnt, S - 1) - base;
+      }
+    }
+  } else if (Lam > POISSON_ICDF_MAX_LAMBDA) {
+    // dense regime: independent Poisson(rr_s*h) per element, private stream per element
+    int cnt = 0, jl = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      if (s < S && rr[k] > 0.0f) {
+        PhiloxStream rs(a.seed, a.offset, (uint64_t)rowc, 1024u + 16u * (uint32_t)s);
+        const int ks = poisson_any(rr[k] * a.h, rs);
+        cnt += min(ks, 1 << 20);
+        jl += min(ks, 1 << 20) * (s - base);
+      }
+    }
+    cnt = grp_sum_i(cnt, G);
+    jl = grp_sum_i(jl, G);
+    jump = (ordinal || cnt <= 1) ? jl : 0;
+  }
+  if (live && li == 0) {
+    const int xn = min(max(xv + jump, 0), S - 1);
+    a.out_x[row] = xn;
+    if (a.out_changed && xn != xv) atomicAdd(a.out_changed, 1);
+  }
+}
+
+static int launch_rows(const StepArgs& a0, void* stream) {
+  StepArgs a = a0;
+  int G = 1;
+  while (G < a.S && G < 64) G <<= 1;
+  a.G = G;
+  const int ept_need = (a.S + G - 1) / G;
+  const int64_t R = (int64_t)a.N * a.D;
+  const int rows_per_wg = 4 * (64 / G);
+  const int64_t grid = (R + rows_per_wg - 1) / rows_per_wg;
+  CTDD_REQUIRE(grid > 0 && grid < (1ll << 31), CTDD_ERANGE, "rows out of range: %lld", (long long)R);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g((unsigned)grid), b(256);
+  if (ept_need <= 1) hipLaunchKernelGGL(k_rows<1>, g, b, 0, st, a);
+  else if (ept_need <= 2) hipLaunchKernelGGL(k_rows<2>, g, b, 0, st, a);
+  else if (ept_need <= 4) hipLaunchKernelGGL(k_rows<4>, g, b, 0, st, a);
+  else if (ept_need <= 8) hipLaunchKernelGGL(k_rows<8>, g, b, 0, st, a);
+  else hipLaunchKernelGGL(k_rows<16>, g, b, 0, st, a);
+  return finish_launch("k_rows");
+}
+
+static int check_common(const void* logits, const void* x, int N, int D, int S) {
+  CTDD_REQUIRE(logits && x, CTDD_EINVAL, "null logits/x");
+  CTDD_REQUIRE(N > 0 && D > 0, CTDD_EINVAL, "N=%d D=%d must be positive", N, D);
+  CTDD_REQUIRE(S >= 2 && S <= CTDD_MAX_S, CTDD_ERANGE, "S=%d outside [2,%d]", S, CTDD_MAX_S);
+  return CTDD_OK;
+}
+
+static int check_branch(int branch, int logit_type, const void* qt0, const void* rate) {
+  CTDD_REQUIRE(branch == CTDD_BRANCH_CTELBO || branch == CTDD_BRANCH_CRM, CTDD_EINVAL, "unknown branch %d", branch);
+  CTDD_REQUIRE(logit_type >= 0 && logit_type <= 2, CTDD_EINVAL, "unknown logit_type %d", logit_type);
+  CTDD_REQUIRE(rate, CTDD_EINVAL, "null rate table");
+  CTDD_REQUIRE(qt0 || (branch == CTDD_BRANCH_CRM && logit_type == CTDD_LOGIT_DIRECT), CTDD_EINVAL,
+               "qt0 table required for this branch/logit_type");
+  return CTDD_OK;
+}
+
+}  // namespace ctdd
+
+using namespace ctdd;
+
+// steps_s256.hip: fast path, returns 1 when it handled the call
+namespace ctdd { int try_s256(const StepArgs& a, void* stream, int* status); }
+
+extern "C" int ctdd_logprob(const float* logits, const int32_t* x, const float* qt0, const int32_t* tidx,
+                            int logit_type, int N, int D, int S, float* out_ll_all, float* out_ll_xt,
+                            void* stream) {
+  if (int rc = check_common(logits, x, N, D, S)) return rc;
+  CTDD_REQUIRE(out_ll_all && out_ll_xt, CTDD_EINVAL, "null output");
+  CTDD_REQUIRE(logit_type >= 0 && logit_type <= 2, CTDD_EINVAL, "unknown logit_type %d", logit_type);
+  CTDD_REQUIRE(qt0 || logit_type == CTDD_LOGIT_DIRECT, CTDD_EINVAL, "qt0 required");
+  StepArgs a{};
+  a.logits = logits; a.x = x; a.qt0 = qt0; a.tidx = tidx; a.N = N; a.D = D; a.S = S;
+  a.branch = CTDD_BRANCH_CRM; a.logit_type = logit_type; a.mode = MODE_LOGPROB;
+  a.out_a = out_ll_all; a.out_b = out_ll_xt;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_reverse_rates(int branch, int logit_type, const float* logits, const int32_t* x,
+                                  const float* qt0, const float* rate, const int32_t* tidx, float eps,
+                                  int N, int D, int S, float* out_rates, float* out_ratio, void* stream) {
+  if (int rc = check_common(logits, x, N, D, S)) return rc;
+  if (int rc = check_branch(branch, logit_type, qt0, rate)) return rc;
+  CTDD_REQUIRE(out_rates, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = logits; a.x = x; a.qt0 = qt0; a.rate = rate; a.tidx = tidx; a.beta = 1.0f; a.eps = eps;
+  a.N = N; a.D = D; a.S = S; a.branch = branch; a.logit_type = logit_type; a.mode = MODE_RATES;
+  a.out_a = out_rates; a.out_b = out_ratio;
+  int st;
+  if (try_s256(a, stream, &st)) return st;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_tauleap_draw(const float* rates, const int32_t* x, const int32_t* x_base, float h,
+                                 uint32_t flags, uint64_t seed, uint64_t offset, int N, int D, int S,
+                                 int32_t* out_x, int32_t* out_changed, void* stream) {
+  if (int rc = check_common(rates, x, N, D, S)) return rc;
+  CTDD_REQUIRE(out_x, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = rates; a.x = x; a.x_base = x_base; a.h = h; a.flags = flags & CTDD_STEP_ORDINAL;
+  a.seed = seed; a.offset = offset; a.N = N; a.D = D; a.S = S; a.mode = MODE_DRAW_ONLY;
+  a.out_x = out_x; a.out_changed = out_changed;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_tauleap_step(int branch, int logit_type, const float* logits, const int32_t* x,
+                                 const int32_t* x_base, const float* qt0, const float* base_rate,
+                                 float beta, float eps, float h, uint32_t flags, uint64_t seed,
+                                 uint64_t offset, int N, int D, int S, int32_t* out_x,
+                                 int32_t* out_changed, void* stream) {
+  if (int rc = check_common(logits, x, N, D, S)) return rc;
+  if (int rc = check_branch(branch, logit_type, qt0, base_rate)) return rc;
+  CTDD_REQUIRE(out_x, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = logits; a.x = x; a.x_base = x_base; a.qt0 = qt0; a.rate = base_rate; a.beta = beta;
+  a.eps = eps; a.h = h; a.flags = flags; a.seed = seed; a.offset = offset; a.N = N; a.D = D; a.S = S;
+  a.branch = branch; a.logit_type = logit_type; a.mode = MODE_TAULEAP;
+  a.out_x = out_x; a.out_changed = out_changed;
+  int st;
+  if (try_s256(a, stream, &st)) return st;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_lbjf_step(int branch, int logit_type, const float* logits, const int32_t* x,
+                              const float* qt0, const float* base_rate, float beta, float eps, float h,
+                              uint32_t flags, const float* E, uint64_t seed, uint64_t offset,
+                              int N, int D, int S, int32_t* out_x, float* out_probs,
+                              int32_t* out_changed, void* stream) {
+  if (int rc = check_common(logits, x, N, D, S)) return rc;
+  if (int rc = check_branch(branch, logit_type, qt0, base_rate)) return rc;
+  CTDD_REQUIRE(out_x, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = logits; a.x = x; a.qt0 = qt0; a.rate = base_rate; a.beta = beta; a.eps = eps; a.h = h;
+  a.flags = flags; a.E = E; a.seed = seed; a.offset = offset; a.N = N; a.D = D; a.S = S;
+  a.branch = branch; a.logit_type = logit_type; a.mode = MODE_LBJF;
+  a.out_x = out_x; a.out_a = out_probs; a.out_changed = out_changed;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_midpoint_predict(int branch, int logit_type, const float* logits, const int32_t* x,
+                                     const float* qt0, const float* base_rate, float beta, float eps,
+                                     float h, int N, int D, int S, int32_t* out_x, void* stream) {
+  if (int rc = check_common(logits, x, N, D, S)) return rc;
+  if (int rc = check_branch(branch, logit_type, qt0, base_rate)) return rc;
+  CTDD_REQUIRE(out_x, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = logits; a.x = x; a.qt0 = qt0; a.rate = base_rate; a.beta = beta; a.eps = eps;
+  a.h = (float)(0.5 * (double)h);   // 0.5*h evaluated in double, then cast (sampling.py:437-439)
+  a.N = N; a.D = D; a.S = S; a.branch = branch; a.logit_type = logit_type; a.mode = MODE_MIDPOINT;
+  a.out_x = out_x;
+  return launch_rows(a, stream);
+}

@@ -1,0 +1,228 @@
+"""ctypes binding of the C ABI declared in include/ctdd.h.
+
+torch is used for device memory and streams only: every wrapper checks dtype / device /
+contiguity, passes raw device pointers + the current HIP stream, and raises CtddError with the
+library's message on a non-zero status.  There is NO fallback: if libctdd.so is missing or an
+operand is not on a GPU the call fails loudly (the CPU restatement lives in /oracle and is test
+infrastructure only).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+BRANCH_CTELBO, BRANCH_CRM = 0, 1
+LOGIT_TYPES = {"direct": 0, "reverse_prob": 1, "reverse_logscale": 2}
+STEP_ORDINAL, STEP_CORRECTOR = 1, 2
+
+
+class CtddError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libctdd.so")
+
+
+_P, _I, _F, _U64, _U32, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_int64
+_SIGS = {
+    "ctdd_abi_version": ([], _I),
+    "ctdd_last_error": ([], C.c_char_p),
+    "ctdd_rate_table": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P], _I),
+    "ctdd_noise_categorical": ([_P, _P, _P, _P, _U64, _U64, _I, _I, _I, _P, _P], _I),
+    "ctdd_xtilde_sample": ([_P, _P, _P, _P, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_logprob": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
+    "ctdd_reverse_rates": ([_I, _I, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P], _I),
+    "ctdd_tauleap_apply": ([_P, _P, _P, _I, _I, _I, _I, _P, _P, _P], _I),
+    "ctdd_tauleap_draw": ([_P, _P, _P, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
+    "ctdd_tauleap_step": ([_I, _I, _P, _P, _P, _P, _P, _F, _F, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
+    "ctdd_lbjf_step": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _U32, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_midpoint_predict": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _P, _P], _I),
+    "ctdd_argmax": ([_P, _I, _I, _I, _P, _P], _I),
+    "ctdd_initial_samples": ([_P, _U64, _U64, _I, _I, _I, _P, _P], _I),
+    "ctdd_philox_uniform": ([_U64, _U64, _I64, _I, _P, _P], _I),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def load():
+    """dlopen libctdd.so once; raise (never fall back) when it is absent."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise CtddError(f"{path} not found: build it with `python __graft_entry__.py` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(path)
+        for name, (argt, rest) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argt, rest
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(t, dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise CtddError(f"{name}: expected a torch tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise CtddError(f"{name}: must live on a GPU (got {t.device}); libctdd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise CtddError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise CtddError(f"{name}: must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().ctdd_last_error().decode(errors="replace")
+        raise CtddError(f"{what} failed with status {rc}: {msg}")
+
+
+f32, i32 = torch.float32, torch.int32
+
+
+def rate_table(eigvecs, right, eigvals, base_rate, integral, beta, S, normalise, clamp_below=1e-8,
+               want_qt0=True, want_qt0T=False, want_rate=False, want_noise_probs=False):
+    nT = integral.numel()
+    dev = integral.device
+    mk = lambda want: torch.empty((nT, S, S), dtype=f32, device=dev) if want else None
+    q, qT, r, pn = mk(want_qt0), mk(want_qt0T), mk(want_rate), mk(want_noise_probs)
+    rc = load().ctdd_rate_table(_ptr(eigvecs, f32, "eigvecs"), _ptr(right, f32, "right"), _ptr(eigvals, f32, "eigvals"),
+                                _ptr(base_rate, f32, "base_rate"), _ptr(integral, f32, "integral"),
+                                _ptr(beta, f32, "beta"), nT, S, int(bool(normalise)), float(clamp_below),
+                                _ptr(q), _ptr(qT), _ptr(r), _ptr(pn), _stream())
+    _check(rc, "ctdd_rate_table")
+    return q, qT, r, pn
+
+
+def noise_categorical(probs, x0, tidx=None, E=None, seed=0, offset=0):
+    B, D = x0.shape
+    S = probs.shape[-1]
+    out = torch.empty((B, D), dtype=i32, device=x0.device)
+    rc = load().ctdd_noise_categorical(_ptr(probs, f32, "probs"), _ptr(tidx, i32, "tidx"), _ptr(x0, i32, "x0"),
+                                       _ptr(E, f32, "E"), seed, offset, B, D, S, _ptr(out), _stream())
+    _check(rc, "ctdd_noise_categorical")
+    return out
+
+
+def xtilde_sample(rate, x_t, tidx=None, E_dim=None, E_val=None, seed=0, offset=0):
+    B, D = x_t.shape
+    S = rate.shape[-1]
+    dev = x_t.device
+    dims = torch.empty((B,), dtype=i32, device=dev)
+    newval = torch.empty((B,), dtype=i32, device=dev)
+    xt = torch.empty((B, D), dtype=i32, device=dev)
+    rc = load().ctdd_xtilde_sample(_ptr(rate, f32, "rate"), _ptr(tidx, i32, "tidx"), _ptr(x_t, i32, "x_t"),
+                                   _ptr(E_dim, f32, "E_dim"), _ptr(E_val, f32, "E_val"), seed, offset, B, D, S,
+                                   _ptr(dims), _ptr(newval), _ptr(xt), _stream())
+    _check(rc, "ctdd_xtilde_sample")
+    return dims, newval, xt
+
+
+def logprob(logits, x, qt0, logit_type, tidx=None):
+    N, D, S = logits.shape
+    ll_all = torch.empty_like(logits)
+    ll_xt = torch.empty((N, D), dtype=f32, device=logits.device)
+    rc = load().ctdd_logprob(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(qt0, f32, "qt0"),
+                             _ptr(tidx, i32, "tidx"), LOGIT_TYPES[logit_type], N, D, S, _ptr(ll_all), _ptr(ll_xt),
+                             _stream())
+    _check(rc, "ctdd_logprob")
+    return ll_all, ll_xt
+
+
+def reverse_rates(branch, logit_type, logits, x, qt0, rate, eps, tidx=None, want_ratio=True):
+    N, D, S = logits.shape
+    rr = torch.empty_like(logits)
+    ratio = torch.empty_like(logits) if want_ratio else None
+    rc = load().ctdd_reverse_rates(branch, LOGIT_TYPES[logit_type], _ptr(logits, f32, "logits"), _ptr(x, i32, "x"),
+                                   _ptr(qt0, f32, "qt0"), _ptr(rate, f32, "rate"), _ptr(tidx, i32, "tidx"),
+                                   float(eps), N, D, S, _ptr(rr), _ptr(ratio), _stream())
+    _check(rc, "ctdd_reverse_rates")
+    return rr, ratio
+
+
+def tauleap_apply(x, jump_nums, is_ordinal, x_base=None, changed=None):
+    N, D, S = jump_nums.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    rc = load().ctdd_tauleap_apply(_ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"), _ptr(jump_nums, f32, "jump_nums"),
+                                   int(bool(is_ordinal)), N, D, S, _ptr(out), _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_tauleap_apply")
+    return out
+
+
+def tauleap_draw(rates, x, h, is_ordinal, seed, offset, x_base=None, changed=None):
+    N, D, S = rates.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    rc = load().ctdd_tauleap_draw(_ptr(rates, f32, "rates"), _ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"), float(h),
+                                  STEP_ORDINAL if is_ordinal else 0, seed, offset, N, D, S, _ptr(out),
+                                  _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_tauleap_draw")
+    return out
+
+
+def tauleap_step(branch, logit_type, logits, x, qt0, base_rate, beta, eps, h, flags, seed, offset,
+                 x_base=None, out=None, changed=None):
+    N, D, S = logits.shape
+    if out is None:
+        out = torch.empty((N, D), dtype=i32, device=x.device)
+    rc = load().ctdd_tauleap_step(branch, LOGIT_TYPES[logit_type], _ptr(logits, f32, "logits"), _ptr(x, i32, "x"),
+                                  _ptr(x_base, i32, "x_base"), _ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"),
+                                  float(beta), float(eps), float(h), int(flags), seed, offset, N, D, S,
+                                  _ptr(out, i32, "out"), _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_tauleap_step")
+    return out
+
+
+def lbjf_step(branch, logit_type, logits, x, qt0, base_rate, beta, eps, h, flags=0, E=None, seed=0, offset=0,
+              want_probs=False, changed=None):
+    N, D, S = logits.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    probs = torch.empty_like(logits) if want_probs else None
+    rc = load().ctdd_lbjf_step(branch, LOGIT_TYPES[logit_type], _ptr(logits, f32, "logits"), _ptr(x, i32, "x"),
+                               _ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), float(beta), float(eps),
+                               float(h), int(flags), _ptr(E, f32, "E"), seed, offset, N, D, S, _ptr(out), _ptr(probs),
+                               _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_lbjf_step")
+    return (out, probs) if want_probs else out
+
+
+def midpoint_predict(branch, logit_type, logits, x, qt0, base_rate, beta, eps, h):
+    N, D, S = logits.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    rc = load().ctdd_midpoint_predict(branch, LOGIT_TYPES[logit_type], _ptr(logits, f32, "logits"), _ptr(x, i32, "x"),
+                                      _ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), float(beta),
+                                      float(eps), float(h), N, D, S, _ptr(out), _stream())
+    _check(rc, "ctdd_midpoint_predict")
+    return out
+
+
+def argmax(logits):
+    N, D, S = logits.shape
+    out = torch.empty((N, D), dtype=i32, device=logits.device)
+    _check(load().ctdd_argmax(_ptr(logits, f32, "logits"), N, D, S, _ptr(out), _stream()), "ctdd_argmax")
+    return out
+
+
+def initial_samples(N, D, S, device, seed, offset, cdf=None):
+    out = torch.empty((N, D), dtype=i32, device=device)
+    if not out.is_cuda:
+        raise CtddError("initial_samples: device must be a GPU")
+    _check(load().ctdd_initial_samples(_ptr(cdf, f32, "cdf"), seed, offset, N, D, S, _ptr(out), _stream()),
+           "ctdd_initial_samples")
+    return out
+
+
+def philox_uniform(seed, offset, nrows, nblk, device):
+    out = torch.empty((nrows, nblk * 4), dtype=f32, device=device)
+    _check(load().ctdd_philox_uniform(seed, offset, nrows, nblk, _ptr(out), _stream()), "ctdd_philox_uniform")
+    return out

@@ -1,0 +1,148 @@
+/* ctdd.h -- C ABI of libctdd.so: the MI355X (gfx950) engine for the tauLDR / SDDM hot path.
+ *
+ * Drop-in boundary: the reference exposes this path through a Python registry
+ * API (TAUnSDDM/lib/{models,losses,sampling,training}), not an FFI.  The host-side mirror of
+ * that API lives in continuous-time-diffusion-models-for-discrete-data_amd/lib and binds the
+ * entry points below with ctypes (INTEGRATION.md shows the stub).  Each entry point names the
+ * reference code it replaces (paths relative to /root/reference/TAUnSDDM).
+ *
+ * Conventions
+ *  - every pointer is a caller-owned DEVICE buffer (hipMalloc / torch CUDA storage) unless the
+ *    name ends in _host; nothing is allocated, retained or freed by the library;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
+ *  - return value: 0 on success, negative CTDD_E* on failure; ctdd_last_error() gives the
+ *    message of the calling thread's last failure.  No exceptions cross the ABI;
+ *  - layouts are dense row-major: logits (N,D,S) f32 with S contiguous, states (N,D) int32,
+ *    tables (nT,S,S) f32;
+ *  - randomness is explicit: either a noise tensor supplied by the caller, or a Philox4x32-10
+ *    (seed, offset) pair; counter = (row_lo,row_hi,offset,draw), key = seed (csrc/philox.hpp).
+ */
+#ifndef CTDD_H
+#define CTDD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTDD_OK 0
+#define CTDD_EINVAL (-22)   /* bad argument (null pointer, size out of range, unknown enum) */
+#define CTDD_ERANGE (-34)   /* size not supported by this build (e.g. S > CTDD_MAX_S)      */
+#define CTDD_EHIP (-5)      /* HIP runtime error at launch                                  */
+
+#define CTDD_MAX_S 1024
+
+/* logit_type of the SDDM branch (lib/models/model_utils.py:30-60) */
+#define CTDD_LOGIT_DIRECT 0
+#define CTDD_LOGIT_REVERSE_PROB 1
+#define CTDD_LOGIT_REVERSE_LOGSCALE 2
+
+/* reverse-rate branch of get_reverse_rates (lib/sampling/sampling.py:31-78) */
+#define CTDD_BRANCH_CTELBO 0   /* loss in {CTElbo, NLL, CTElboLambda}: lines 32-59 */
+#define CTDD_BRANCH_CRM 1      /* everything else: lines 61-73                      */
+
+/* flags of ctdd_tauleap_step */
+#define CTDD_STEP_ORDINAL 1u     /* cfg.sampler.is_ordinal (sampling.py:135-138)                 */
+#define CTDD_STEP_CORRECTOR 2u   /* add rate[x][s] to R^ (corrector, sampling.py:182-198)        */
+
+int ctdd_abi_version(void);
+const char* ctdd_last_error(void);
+
+/* K1  q_{t|0} and R_t tables for nT times.
+ * Replaces {GaussianTargetRate,UniformRate,UniformVariantRate,BirthDeathForwardBase}.transition/
+ * .rate/.transit_between (lib/models/forward_model.py:43-75,95-129,166-204,252-306):
+ *   P_t = V diag(exp(integral[t] * eigvals)) W ; optional row-normalise ; entries < clamp_below -> 0
+ *   R_t = beta[t] * base_rate
+ * W = inv_eigvecs (or V^T).  Any output pointer may be NULL.  out_qt0T[t][x][s0] = P_t[s0][x];
+ * out_noise_probs[t][x0][:] = the probabilities torch's Categorical(logits=where(row<=0,-1e9,
+ * log row)) hands to multinomial (lib/losses/losses.py:46-55). */
+int ctdd_rate_table(const float* eigvecs, const float* right, const float* eigvals,
+                    const float* base_rate, const float* integral, const float* beta,
+                    int nT, int S, int normalise, float clamp_below,
+                    float* out_qt0, float* out_qt0T, float* out_rate, float* out_noise_probs,
+                    void* stream);
+
+/* K2  x_t ~ Categorical(probs[tidx[b]][x0[b,d]][:]) for every (b,d)  (lib/losses/losses.py:46-59,
+ * 859-874, 1211-1225).  One draw per row as ATen does it: argmax_s(p_s / E_s), first index on
+ * ties.  E (B*D,S) explicit Exp(1) noise, or NULL to draw E = -log(u) from Philox(seed,offset).
+ * tidx may be NULL (table b for batch row b). */
+int ctdd_noise_categorical(const float* probs, const int32_t* tidx, const int32_t* x0,
+                           const float* E, uint64_t seed, uint64_t offset,
+                           int B, int D, int S, int32_t* out_xt, void* stream);
+
+/* K3  one-jump neighbour x~ of x_t (lib/losses/losses.py:61-101): per batch row pick the
+ * dimension with weight w_d = sum_{s != x_d} rate[t][x_d][s] and the new value from row
+ * rate[t][x_dim][:] (own state excluded), both by exponential race.  E_dim (B,D), E_val (B,S)
+ * explicit, or both NULL for Philox.  rate is (nT,S,S) = R_t; tidx as above. */
+int ctdd_xtilde_sample(const float* rate, const int32_t* tidx, const int32_t* x_t,
+                       const float* E_dim, const float* E_val, uint64_t seed, uint64_t offset,
+                       int B, int D, int S, int32_t* out_dims, int32_t* out_newval,
+                       int32_t* out_xtilde, void* stream);
+
+/* A6  SDDM log-probabilities (lib/models/model_utils.py:30-60): ll_all (N,D,S), ll_xt (N,D). */
+int ctdd_logprob(const float* logits, const int32_t* x, const float* qt0, const int32_t* tidx,
+                 int logit_type, int N, int D, int S, float* out_ll_all, float* out_ll_xt,
+                 void* stream);
+
+/* K4/K5  reverse rates R^ and ratio, own state NOT zeroed (lib/sampling/sampling.py:31-78).
+ * qt0/rate are (nT,S,S); tidx[n] picks the table of batch row n (NULL: table 0 for all rows,
+ * the sampling case where every row shares t).  out_ratio may be NULL. */
+int ctdd_reverse_rates(int branch, int logit_type, const float* logits, const int32_t* x,
+                       const float* qt0, const float* rate, const int32_t* tidx, float eps,
+                       int N, int D, int S, float* out_rates, float* out_ratio, void* stream);
+
+/* K6a  tau-leaping state update from explicit jump counts (lib/sampling/sampling.py:135-160,
+ * 478-503): x_new = clamp(x + sum_s k_s (s - base), 0, S-1); base = x unless x_base given
+ * (midpoint stage 2).  Non-ordinal: dimensions with more than one jump are left unchanged.
+ * out_changed (1 int32, may be NULL) accumulates #(x_new != x). */
+int ctdd_tauleap_apply(const int32_t* x, const int32_t* x_base, const float* jump_nums,
+                       int is_ordinal, int N, int D, int S, int32_t* out_x, int32_t* out_changed,
+                       void* stream);
+
+/* K6b  Poisson jump draw + update from given rates (N,D,S) (own state is masked inside).
+ * Draw rule (distribution-equal to independent Poisson(rate_s*h) per s, csrc/draw.hpp):
+ * K ~ Poisson(h * sum_s rate_s) then K destinations ~ Categorical(rate). */
+int ctdd_tauleap_draw(const float* rates, const int32_t* x, const int32_t* x_base, float h,
+                      uint32_t flags, uint64_t seed, uint64_t offset, int N, int D, int S,
+                      int32_t* out_x, int32_t* out_changed, void* stream);
+
+/* K4+K6 fused: one tau-leaping (or corrector) step straight from the logits
+ * (TauL.sample body, lib/sampling/sampling.py:119-160 and 165-221; PCTauL 559-640;
+ * MidPointTauL stage 2, 459-508).  R^ never touches HBM.  beta = scalar R_t = beta*base_rate. */
+int ctdd_tauleap_step(int branch, int logit_type, const float* logits, const int32_t* x,
+                      const int32_t* x_base, const float* qt0, const float* base_rate, float beta,
+                      float eps, float h, uint32_t flags, uint64_t seed, uint64_t offset,
+                      int N, int D, int S, int32_t* out_x, int32_t* out_changed, void* stream);
+
+/* K7  Euler / LBJF step (lib/sampling/sampling.py:278-293, corrector 296-341): posterior row
+ * P = h*R^*(1-onehot) + clip(1-h*sum,0)*onehot, normalised, then x_new ~ Categorical(log(P+1e-35))
+ * by exponential race.  E (N*D,S) explicit or NULL for Philox.  out_probs (N,D,S) may be NULL. */
+int ctdd_lbjf_step(int branch, int logit_type, const float* logits, const int32_t* x,
+                   const float* qt0, const float* base_rate, float beta, float eps, float h,
+                   uint32_t flags, const float* E, uint64_t seed, uint64_t offset,
+                   int N, int D, int S, int32_t* out_x, float* out_probs, int32_t* out_changed,
+                   void* stream);
+
+/* K8  midpoint predictor (lib/sampling/sampling.py:417-453):
+ * x' = clip(x + round_half_even(0.5*h*sum_s R^_s (s-x)), 0, S-1) with own state excluded. */
+int ctdd_midpoint_predict(int branch, int logit_type, const float* logits, const int32_t* x,
+                          const float* qt0, const float* base_rate, float beta, float eps, float h,
+                          int N, int D, int S, int32_t* out_x, void* stream);
+
+/* K10 final denoise: argmax_s softmax(logits) = first argmax of logits (sampling.py:223-229). */
+int ctdd_argmax(const float* logits, int N, int D, int S, int32_t* out_x, void* stream);
+
+/* A7  initial state (lib/sampling/sampling.py:14-28): uniform randint or inverse-CDF draws from
+ * a host-computed pmf cdf (S floats, device).  cdf NULL = uniform. */
+int ctdd_initial_samples(const float* cdf, uint64_t seed, uint64_t offset, int N, int D, int S,
+                         int32_t* out_x, void* stream);
+
+/* test hook: the raw uniforms a kernel would see: out[row*4*nblk + 4*j + i]. */
+int ctdd_philox_uniform(uint64_t seed, uint64_t offset, int64_t nrows, int nblk, float* out,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTDD_H */

@@ -41,8 +41,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def u01(r):
-    """uint32 -> float32 in the open interval (0,1): (r>>8)*2^-24 + 2^-25 (exact in fp32)."""
-    return ((r >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24) + np.float32(2.0**-25)).astype(np.float32)
+    """uint32 -> float32 in the open interval (0,1): ((r>>9) + 0.5) * 2^-23.
+    Every step is exact in fp32 (24 significant bits); min 2^-24, max 1-2^-24."""
+    return (((r >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0**-23)).astype(np.float32)
 
 
 def exp1(r):
@@ -101,3 +102,44 @@ def categorical_icdf(w, u):
     idx = np.minimum(idx, w.shape[-1] - 1)
     margin = np.min(np.abs(cs - target), axis=-1) / np.maximum(tot[..., 0], 1e-300)
     return idx.astype(np.int64), margin
+
+
+def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
+    """CPU replay of the kernels' jump draw (csrc/steps_generic.hip, MODE_TAULEAP):
+    rates (N,D,S) float32 reverse rates (own state is masked here), x (N,D) int.
+    K ~ Poisson(h*sum_s r_s) from uniform #0 of the row's stream; K destinations by inverse CDF
+    over r in s order from uniforms #1.. ; non-ordinal rows with K>1 stay put.
+    Rows with h*sum > POISSON_ICDF_MAX_LAMBDA use the per-element path and are flagged undecided.
+    Returns (x_new int64 (N,D), decided bool (N,D)) -- `decided` is False where a float
+    comparison sits within reassociation noise of a boundary (or on the dense path)."""
+    r = np.array(rates, dtype=np.float32, copy=True)
+    N, D, S = r.shape
+    x = np.asarray(x).astype(np.int64)
+    base = x if x_base is None else np.asarray(x_base).astype(np.int64)
+    np.put_along_axis(r, x[..., None], 0.0, axis=-1)
+    r = r.reshape(N * D, S)
+    T = r.astype(np.float64).sum(-1)
+    lam = (T * np.float64(np.float32(h))).astype(np.float32)
+    rows = np.arange(N * D, dtype=np.uint64)
+    nblk = 1 + (POISSON_ICDF_KMAX + 4) // 4
+    U = row_uniforms(rows, offset, seed, nblk)                     # (R, 4*nblk)
+    K, margin = poisson_icdf(lam, U[:, 0])
+    K = np.where(lam > 0, K, 0)
+    decided = (margin > 1e-5 * np.maximum(1.0, lam)) | (lam == 0)
+    dense = lam > POISSON_ICDF_MAX_LAMBDA
+    decided &= ~dense
+    xf, bf = x.reshape(-1), base.reshape(-1)
+    jump = np.zeros(N * D, dtype=np.int64)
+    for j in range(int(K[~dense].max()) if (~dense).any() else 0):
+        act = (K > j) & ~dense
+        if not act.any():
+            break
+        idx, mg = categorical_icdf(r[act], U[act, 1 + j])
+        jump[act] += idx - bf[act]
+        d = decided[act]
+        d &= mg > 1e-5
+        decided[act] = d
+    if not is_ordinal:
+        jump = np.where(K > 1, 0, jump)
+    xn = np.clip(xf + jump, 0, S - 1)
+    return xn.reshape(N, D), decided.reshape(N, D)
