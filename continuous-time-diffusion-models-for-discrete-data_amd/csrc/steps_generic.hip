@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   const int tbl = a.tidx ? a.tidx[n] : 0;
   const float* qt0 = a.qt0 ? a.qt0 + (size_t)tbl * S * S : nullptr;
   const float* rate = a.rate ? a.rate + (size_t)tbl * S * S : nullptr;
-  int xv = a.x[rowc];
-  xv = min(max(xv, 0), S - 1);
+  // xcur = state the move is added to; xv = state the rates are evaluated at and measured from
+  // (x' in stage 2 of the midpoint sampler, sampling.py:459-503; otherwise the same state)
+  const int xcur = min(max(a.x[rowc], 0), S - 1);
+  const int xv = a.x_base ? min(max(a.x_base[rowc], 0), S - 1) : xcur;
   const float* lrow = a.logits + (size_t)rowc * S;
 
   float rr[EPT];     // reverse rates (own state NOT zeroed)
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     if ((a.flags & CTDD_STEP_CORRECTOR) && s < S) rr[k] += a.beta * rate[(size_t)xv * S + s];
     if (s == xv || s >= S) rr[k] = 0.0f;
   }
-  const int base = a.x_base ? min(max(a.x_base[rowc], 0), S - 1) : xv;
+  const int base = xv;
 
   if (a.mode == MODE_MIDPOINT) {
     float acc = 0.0f;
@@ -357,9 +359,10 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     jump = (ordinal || cnt <= 1) ? jl : 0;
   }
   if (live && li == 0) {
-    const int xn = min(max(xv + jump, 0), S - 1);
+    const int xn = min(max(xcur + jump, 0), S - 1);
     a.out_x[row] = xn;
-    if (a.out_changed && xn != xv) atomicAdd(a.out_changed, 1);
+    const bool moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
+    if (a.out_changed && moved) atomicAdd(a.out_changed, 1);
   }
 }
 

@@ -16,7 +16,7 @@ _LIB = None
 
 BRANCH_CTELBO, BRANCH_CRM = 0, 1
 LOGIT_TYPES = {"direct": 0, "reverse_prob": 1, "reverse_logscale": 2}
-STEP_ORDINAL, STEP_CORRECTOR = 1, 2
+STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW = 1, 2, 4
 
 
 class CtddError(RuntimeError):

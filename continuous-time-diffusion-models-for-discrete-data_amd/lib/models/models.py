@@ -1,0 +1,208 @@
+"""Model objects = EMA (+) score-network wrapper (+) forward CTMC process, registered under the
+reference's class names (lib/models/models.py:192-299, 495-525, 730-823, 832-1082).
+
+A model is callable `model(x, t) -> (B, D, S)` fp32 logits and exposes `.transition/.rate/
+.rate_mat/.transit_between`, `.device`, `.S`, `.update_ema()`, EMA-swapping `.train()/.eval()` and a
+`state_dict()` carrying `ema_decay / ema_num_updates / ema_shadow_params`, as the reference does.
+Only the wrappers named by the BASELINE configs are built."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+import lib.models.model_utils as model_utils
+from lib.models.forward_model import GaussianTargetRate, UniformRate, UniformVariantRate, BirthDeathForwardBase  # noqa: F401
+from lib.networks import unet
+
+
+def _maybe_ddp(net, cfg, rank):
+    return DDP(net, device_ids=[rank]) if cfg.distributed else net
+
+
+def logistic_logits(mu, log_scale, S, fix_logistic, eps=1e-6):
+    """Truncated-logistic head (D3PM, arXiv:2107.03006 app. A; models.py:249-283): the S bin
+    log-probabilities of a logistic(mu, exp(log_scale-2)) over equal bins of [-1, 1].
+    mu, log_scale: (..., 1) broadcast against S bins -> (..., S)."""
+    inv_scale = torch.exp(-(log_scale - 2))
+    width = 2.0 / S
+    centres = torch.linspace(-1.0 + width / 2, 1.0 - width / 2, S, device=mu.device)
+    left = (centres - width / 2 - mu) * inv_scale
+    right = (centres + width / 2 - mu) * inv_scale
+    lcdf_l, lcdf_r = F.logsigmoid(left), F.logsigmoid(right)
+    lme = lambda a, b: a + torch.log1p(-torch.exp(b - a) + eps)       # log(exp(a) - exp(b)), b < a
+    logits = lme(lcdf_r, lcdf_l)
+    if fix_logistic:
+        logits = torch.min(logits, lme(-left + lcdf_l, -right + lcdf_r))
+    return logits
+
+
+class ImageX0PredBasePaul(nn.Module):
+    """x0-prediction wrapper around the U-Net (models.py:192-299)."""
+
+    def __init__(self, cfg, device, rank=None):
+        super().__init__()
+        self.cfg = cfg
+        m = cfg.model
+        self.fix_logistic = m.fix_logistic
+        self.data_shape = cfg.data.shape
+        self.S = cfg.data.S
+        self.padding = m.padding
+        net = unet.UNet(in_channel=m.input_channels, out_channel=m.input_channels, channel=m.ch,
+                        channel_multiplier=m.ch_mult, n_res_blocks=m.num_res_blocks,
+                        attn_resolutions=m.attn_resolutions, num_heads=m.num_heads, dropout=m.dropout,
+                        model_output=m.model_output, num_classes=cfg.data.S, x_min_max=m.data_min_max,
+                        img_size=cfg.data.image_size + (1 if self.padding else 0)).to(device)
+        self.net = _maybe_ddp(net, cfg, rank)
+        self._engine = None
+
+    def forward(self, x, times):
+        if x.dim() == 2:
+            B, D = x.shape
+            C, H, W = self.data_shape
+            x = x.view(B, C, H, W)
+        else:
+            B, C, H, W = x.shape
+            D = C * H * W
+        if self._use_engine(x):
+            return self._engine_forward(x, times)
+        x = x.float()
+        if self.padding:
+            x = F.pad(x, (0, 1, 0, 1), mode="replicate")
+        out = self.net(x, times)
+        if self.cfg.model.model_output == "logits":
+            logits = out                                              # (B,C,H,W,S)
+        else:
+            mu, log_scale = out
+            logits = logistic_logits(mu.unsqueeze(-1), log_scale.unsqueeze(-1), self.S, self.fix_logistic)
+        if self.padding:
+            logits = logits[:, :, :-1, :-1, :]
+        return logits.reshape(B, D, self.S)
+
+    # -- hand-written HIP inference engine (ctdd/unet_engine.py); training keeps autograd ops
+    def _use_engine(self, x):
+        if torch.is_grad_enabled() or self.training or not x.is_cuda or self.cfg.distributed:
+            return False
+        if getattr(self.cfg.model, "engine", "hip") != "hip":
+            return False
+        try:
+            from ctdd import unet_engine
+        except ImportError:
+            return False
+        return unet_engine.supports(self)
+
+    def _engine_forward(self, x, times):
+        from ctdd import unet_engine
+        if self._engine is None:
+            self._engine = unet_engine.UNetEngine(self)
+        return self._engine(x, times)
+
+
+class HollowTransformer(nn.Module):
+    """SDDM hollow transformer wrapper (models.py:495-525)."""
+
+    def __init__(self, cfg, device, rank=None):
+        super().__init__()
+        from lib.networks import hollow_networks
+        if cfg.model.nets == "bidir_transformer2":
+            net = hollow_networks.BidirectionalTransformer2(cfg, readout_dim=None).to(device)
+        else:
+            raise ValueError(f"only nets='bidir_transformer2' is built (got {cfg.model.nets})")
+        self.net = _maybe_ddp(net, cfg, rank)
+
+    def forward(self, x, times):
+        return self.net(x, times)
+
+
+class EMA:
+    """Exponential moving average of the trainable parameters with train/eval weight swapping
+    (models.py:730-823).  Mixed in FIRST so its state_dict/load_state_dict/train win the MRO."""
+
+    def __init__(self, cfg):
+        self.decay = cfg.model.ema_decay
+        self.device = cfg.device
+        if self.decay < 0.0 or self.decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.shadow_params, self.collected_params, self.num_updates = [], [], 0
+
+    def _trainable(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def init_ema(self):
+        self.shadow_params = [p.clone().detach() for p in self._trainable()]
+
+    def update_ema(self):
+        if len(self.shadow_params) == 0:
+            raise ValueError("Shadow params not initialized before first ema update!")
+        self.num_updates += 1
+        decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        with torch.no_grad():
+            params = self._trainable()
+            # shadow -= (1-decay) * (shadow - param), one fused multi-tensor launch
+            torch._foreach_lerp_(self.shadow_params, [p.detach() for p in params], 1.0 - decay)
+
+    def state_dict(self):
+        sd = nn.Module.state_dict(self)
+        sd["ema_decay"] = self.decay
+        sd["ema_num_updates"] = self.num_updates
+        sd["ema_shadow_params"] = self.shadow_params
+        return sd
+
+    def load_state_dict(self, state_dict):
+        missing, unexpected = nn.Module.load_state_dict(self, state_dict, strict=False)
+        if len(missing) > 0:
+            raise ValueError(f"Missing keys: {missing}")
+        if sorted(unexpected) != ["ema_decay", "ema_num_updates", "ema_shadow_params"]:
+            raise ValueError(f"Unexpected keys: {unexpected}")
+        self.decay = state_dict["ema_decay"]
+        self.num_updates = state_dict["ema_num_updates"]
+        self.shadow_params = state_dict["ema_shadow_params"]
+
+    def move_shadow_params_to_model_params(self):
+        for s, p in zip(self.shadow_params, self._trainable()):
+            p.data.copy_(s.data)
+
+    def move_model_params_to_collected_params(self):
+        self.collected_params = [p.clone() for p in self.parameters()]
+
+    def move_collected_params_to_model_params(self):
+        for c, p in zip(self.collected_params, self.parameters()):
+            p.data.copy_(c.data)
+
+    def train(self, mode=True):
+        if self.training == mode:
+            raise ValueError("Dont call model.train() with the same mode twice! Otherwise EMA parameters may "
+                             f"overwrite original parameters (current {self.training}, requested {mode})")
+        nn.Module.train(self, mode)
+        if mode:
+            if len(self.collected_params) > 0:
+                self.move_collected_params_to_model_params()
+        else:
+            self.move_model_params_to_collected_params()
+            self.move_shadow_params_to_model_params()
+        self._weights_version = getattr(self, "_weights_version", 0) + 1
+        return self
+
+
+def _compose(name, net_cls, rate_cls, doc):
+    """Build `class name(EMA, net_cls, rate_cls)` with the reference's init order and register it."""
+
+    def __init__(self, cfg, device, rank=None):
+        EMA.__init__(self, cfg)
+        net_cls.__init__(self, cfg, device, rank)
+        rate_cls.__init__(self, cfg, device)
+        self.init_ema()
+
+    cls = type(name, (EMA, net_cls, rate_cls), {"__init__": __init__, "__doc__": doc})
+    return model_utils.register_model(cls)
+
+
+# U-Net models: MNIST / CIFAR-10 tauLDR (models.py:942-951), uniform variants (975-992, 851-859)
+GaussianTargetRateImageX0PredEMAPaul = _compose(
+    "GaussianTargetRateImageX0PredEMAPaul", ImageX0PredBasePaul, GaussianTargetRate, "tauLDR U-Net, Gaussian-target CTMC")
+UniformRateUnetEMA = _compose("UniformRateUnetEMA", ImageX0PredBasePaul, UniformRate, "U-Net, uniform CTMC")
+UniVarUnetEMA = _compose("UniVarUnetEMA", ImageX0PredBasePaul, UniformVariantRate, "U-Net, time-warped uniform CTMC")
+UniformRateImageX0PredEMA = _compose("UniformRateImageX0PredEMA", ImageX0PredBasePaul, UniformRate, "U-Net, uniform CTMC")
+# hollow-transformer models: SDDM (models.py:862-869, 954-961, 905-912)
+GaussianHollowEMA = _compose("GaussianHollowEMA", HollowTransformer, GaussianTargetRate, "hollow transformer, Gaussian-target CTMC")
+UniVarHollowEMA = _compose("UniVarHollowEMA", HollowTransformer, UniformVariantRate, "hollow transformer, time-warped uniform CTMC")
+UniformHollowEMA = _compose("UniformHollowEMA", HollowTransformer, UniformRate, "hollow transformer, uniform CTMC")

@@ -45,6 +45,7 @@ extern "C" {
 /* flags of ctdd_tauleap_step */
 #define CTDD_STEP_ORDINAL 1u     /* cfg.sampler.is_ordinal (sampling.py:135-138)                 */
 #define CTDD_STEP_CORRECTOR 2u   /* add rate[x][s] to R^ (corrector, sampling.py:182-198)        */
+#define CTDD_STEP_COUNT_RAW 4u   /* out_changed counts the UNCLIPPED move != 0 (sampling.py:505) */
 
 int ctdd_abi_version(void);
 const char* ctdd_last_error(void);
@@ -100,7 +101,9 @@ int ctdd_tauleap_apply(const int32_t* x, const int32_t* x_base, const float* jum
                        int is_ordinal, int N, int D, int S, int32_t* out_x, int32_t* out_changed,
                        void* stream);
 
-/* K6b  Poisson jump draw + update from given rates (N,D,S) (own state is masked inside).
+/* K6b  Poisson jump draw + update from given rates (N,D,S).  The rates belong to the state
+ * x_base (default x): its own entry is masked and moves are measured from it, then added to x
+ * (midpoint stage 2: rates at x', x_new = clip(x + sum k_s (s - x'))).
  * Draw rule (distribution-equal to independent Poisson(rate_s*h) per s, csrc/draw.hpp):
  * K ~ Poisson(h * sum_s rate_s) then K destinations ~ Categorical(rate). */
 int ctdd_tauleap_draw(const float* rates, const int32_t* x, const int32_t* x_base, float h,
@@ -109,7 +112,8 @@ int ctdd_tauleap_draw(const float* rates, const int32_t* x, const int32_t* x_bas
 
 /* K4+K6 fused: one tau-leaping (or corrector) step straight from the logits
  * (TauL.sample body, lib/sampling/sampling.py:119-160 and 165-221; PCTauL 559-640;
- * MidPointTauL stage 2, 459-508).  R^ never touches HBM.  beta = scalar R_t = beta*base_rate. */
+ * MidPointTauL stage 2, 459-508).  R^ never touches HBM.  beta = scalar R_t = beta*base_rate.
+ * logits must be the network output at x_base when x_base is given (else at x). */
 int ctdd_tauleap_step(int branch, int logit_type, const float* logits, const int32_t* x,
                       const int32_t* x_base, const float* qt0, const float* base_rate, float beta,
                       float eps, float h, uint32_t flags, uint64_t seed, uint64_t offset,

@@ -106,7 +106,7 @@ def categorical_icdf(w, u):
 
 def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
     """CPU replay of the kernels' jump draw (csrc/steps_generic.hip, MODE_TAULEAP):
-    rates (N,D,S) float32 reverse rates (own state is masked here), x (N,D) int.
+    rates (N,D,S) float32 reverse rates evaluated at x_base (default x); its own state is masked here.
     K ~ Poisson(h*sum_s r_s) from uniform #0 of the row's stream; K destinations by inverse CDF
     over r in s order from uniforms #1.. ; non-ordinal rows with K>1 stay put.
     Rows with h*sum > POISSON_ICDF_MAX_LAMBDA use the per-element path and are flagged undecided.
@@ -116,7 +116,7 @@ def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
     N, D, S = r.shape
     x = np.asarray(x).astype(np.int64)
     base = x if x_base is None else np.asarray(x_base).astype(np.int64)
-    np.put_along_axis(r, x[..., None], 0.0, axis=-1)
+    np.put_along_axis(r, base[..., None], 0.0, axis=-1)      # own state of the rate-state (x' if given)
     r = r.reshape(N * D, S)
     T = r.astype(np.float64).sum(-1)
     lam = (T * np.float64(np.float32(h))).astype(np.float32)

@@ -1,0 +1,146 @@
+"""GPU: the product samplers (lib.sampling.sampling on libctdd) against the CPU oracle's
+restatement of the reference loops.  Poisson / categorical streams differ (Philox vs torch's
+generator) so parity is distributional: per-step change-rate trajectories and
+final marginals of many samples must agree within sampling error."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import samplers as osamp
+from oracle.forward_process import ForwardProcess
+from oracle.toy_model import ToyModel, toy_logits
+
+
+def _cfg(S, D, sampler, loss="CTElbo", logit_type="direct", **over):
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    c = get_config()
+    c.data.S, c.model.concat_dim = S, D
+    c.loss.name, c.loss.logit_type = loss, logit_type
+    c.sampler.name = sampler
+    c.sampler.num_steps = over.pop("num_steps", 12)
+    c.sampler.num_corrector_steps = over.pop("num_corrector_steps", 0)
+    for k, v in over.items():
+        if k in ("max_t",):
+            c.training[k] = v
+        elif k in ("rate_const", "t_func"):
+            c.model[k] = v
+        else:
+            c.sampler[k] = v
+    return c
+
+
+class DeviceToy:
+    """toy score function + device forward process, duck-typing the product model object."""
+
+    def __init__(self, kind, S, scale=1.0, **p):
+        from ctdd.process import DeviceForwardProcess
+        self.process = DeviceForwardProcess(kind, S, "cuda", **p)
+        self.S, self.device, self.scale = S, torch.device("cuda"), scale
+
+    def __call__(self, x, t):
+        return toy_logits(x, t, self.S, self.scale)
+
+    def transition(self, t):
+        return self.process.transition(t)
+
+    def rate(self, t):
+        return self.process.rate(t)
+
+    def rate_mat(self, y, t):
+        return self.process.rate_mat(y, t)
+
+
+GAUSS = dict(rate_sigma=6.0, Q_sigma=512.0, time_exp=100.0, time_base=3.0)
+
+
+def _two_sample_chi2(a, b, S):
+    ca = np.bincount(a.ravel(), minlength=S).astype(np.float64)
+    cb = np.bincount(b.ravel(), minlength=S).astype(np.float64)
+    m = (ca + cb) > 0
+    k1, k2 = np.sqrt(cb.sum() / ca.sum()), np.sqrt(ca.sum() / cb.sum())
+    return (((k1 * ca - k2 * cb) ** 2)[m] / (ca + cb)[m]).sum(), int(m.sum()) - 1
+
+
+@pytest.mark.parametrize("case", ["taul_ord", "taul_nonord", "taul_corr", "taul_crm", "lbjf", "lbjf_crm_corr",
+                                  "midpoint", "pctaul"])
+def test_sampler_distribution_matches_oracle(case):
+    import lib.sampling.sampling  # noqa: F401
+    import lib.sampling.sampling_utils as su
+    N = 3000
+    spec = {
+        "taul_ord": ("TauL", "gaussian", 16, 10, "CTElbo", "direct", dict(is_ordinal=True), 1.0),
+        "taul_nonord": ("TauL", "gaussian", 16, 10, "CTElbo", "direct", dict(is_ordinal=False), 4.0),
+        "taul_corr": ("TauL", "gaussian", 16, 10, "CTElbo", "direct", dict(corrector_entry_time=0.6, num_corrector_steps=2), 1.0),
+        "taul_crm": ("TauL", "univar", 3, 15, "CatRM", "reverse_prob", dict(is_ordinal=False, initial_dist="uniform", max_t=0.99999), 3.0),
+        "lbjf": ("LBJF", "gaussian", 16, 10, "CTElbo", "direct", dict(), 1.0),
+        "lbjf_crm_corr": ("LBJF", "univar", 3, 15, "CatRMNLL", "reverse_logscale", dict(initial_dist="uniform", max_t=0.99999, corrector_entry_time=0.5, num_corrector_steps=1), 3.0),
+        "midpoint": ("MidPointTauL", "univar", 3, 15, "CatRM", "reverse_prob", dict(is_ordinal=False, initial_dist="uniform", max_t=0.99999), 3.0),
+        "pctaul": ("PCTauL", "gaussian", 16, 10, "CTElbo", "direct", dict(corrector_entry_time=0.7, num_corrector_steps=2, initial_dist="gaussian"), 1.0),
+    }[case]
+    sname, kind, S, D, loss, lt, over, scale = spec
+    params = GAUSS if kind == "gaussian" else dict(rate_const=1.7, t_func="sqrt_cos")
+    if kind == "univar":
+        over = dict(over, rate_const=1.7, t_func="sqrt_cos")
+    cfg = _cfg(S, D, sname, loss, lt, **over)
+    cfg.data.name = "Maze3S"
+    sampler = su.get_sampler(cfg)
+    sampler.seed = 1234
+    out = sampler.sample(DeviceToy(kind, S, scale, **params), N)
+    hip = out if sname == "PCTauL" else out[0]
+    # oracle run (CPU, torch RNG), same sample count
+    proc = ForwardProcess(kind, S, **params)
+    om = ToyModel(proc, S, scale=scale)
+    torch.manual_seed(7)
+    s = cfg.sampler
+    common = dict(min_t=s.min_t, num_steps=s.num_steps, initial_dist=s.initial_dist, eps_ratio=s.eps_ratio)
+    if sname == "TauL":
+        ref = osamp.taul_sample(om, N, D, S, max_t=cfg.training.max_t, init_std=512.0, is_ordinal=s.is_ordinal,
+                                loss_name=loss, logit_type=lt, corrector_entry_time=s.corrector_entry_time,
+                                num_corrector_steps=s.num_corrector_steps, **common)
+    elif sname == "LBJF":
+        ref = osamp.lbjf_sample(om, N, D, S, max_t=cfg.training.max_t, init_std=512.0, loss_name=loss, logit_type=lt,
+                                corrector_entry_time=s.corrector_entry_time, num_corrector_steps=s.num_corrector_steps,
+                                **common)
+    elif sname == "MidPointTauL":
+        ref = osamp.midpoint_sample(om, N, D, S, max_t=cfg.training.max_t, init_std=512.0, is_ordinal=s.is_ordinal,
+                                    loss_name=loss, logit_type=lt, **common)
+    else:
+        ref = (osamp.pctaul_sample(om, N, D, S, corrector_entry_time=s.corrector_entry_time,
+                                   num_corrector_steps=s.num_corrector_steps,
+                                   corrector_step_size_multiplier=s.corrector_step_size_multiplier, **common),)
+    assert hip.shape == ref[0].shape == (N, D) and hip.min() >= 0 and hip.max() < S
+    # final marginals, per dimension group: two-sample chi-square (fixed seeds: deterministic verdict)
+    chi2, dof = _two_sample_chi2(hip, ref[0], S)
+    assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)
+    # mean state per dimension
+    se = np.sqrt(hip.var(0) / N + ref[0].var(0) / N) + 1e-9
+    assert (np.abs(hip.mean(0) - ref[0].mean(0)) / se).max() < 5.5
+    # per-step change-rate trajectory (TauL / LBJF return it as 2nd output, MidPoint as 3rd)
+    if sname in ("TauL", "LBJF"):
+        a, b = np.asarray(out[1]), np.asarray(ref[1])
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() < 0.05 * D + 6 * np.sqrt(D / N)
+    if sname == "MidPointTauL":
+        assert len(out) == 5 and len(out[2]) == len(ref[2])
+        assert np.abs(np.asarray(out[3]) - np.asarray(ref[3])).max() < 0.03      # deterministic predictor stage
+        assert np.abs(np.asarray(out[2]) - np.asarray(ref[2])).max() < 0.03
+
+
+def test_unet_model_samples_end_to_end():
+    """MNIST tauLDR config (small step count): create_model -> TauL.sample on the GPU."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.sampling.sampling  # noqa: F401
+    import lib.sampling.sampling_utils as su
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.sampler.num_steps = 5
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    samples, change_dim = su.get_sampler(cfg).sample(model, 8)
+    assert samples.shape == (8, 784) and samples.dtype.kind == "i"
+    assert samples.min() >= 0 and samples.max() <= 255 and len(change_dim) == 5
+    model.train()
