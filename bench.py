@@ -1,0 +1,190 @@
+"""bench.py -- tau-leaping sample-steps/s on the MNIST tauLDR config (D=784, S=256).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: the exact body of TauL.sample's loop
+(reference lib/sampling/sampling.py:119-160) for `--batch` samples per GPU -- score-network
+forward, then ONE fused libctdd launch (softmax -> S x S ratio contraction -> forward-rate gather
+-> Poisson jump draw -> state update).  Inputs (state x, per-step q_{t|0} tables, random-init
+weights) are resident in HBM before the timed region.  Sampling shards over GPUs with no
+data-path collective: weak scaling, value = all ranks' sample-steps / max-rank time.
+
+The JSON line also carries
+  roofline      the fused tau-leap kernel: algorithmic bytes per sample-step (809 088 B at fp32,
+                SURVEY 8d) x batch / its mean launch duration (HIP events on the launch stream);
+  cpu_baseline  the CPU oracle (checker, never the product) running the same step on host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "continuous-time-diffusion-models-for-discrete-data_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+D, S = 784, 256
+ALGO_BYTES_PER_SAMPLE_STEP = D * S * 4 + D * 4 + D * 4      # fp32 logits + x in + x out
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU (SURVEY 8d: 256)")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(device):
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.sampling.sampling  # noqa: F401
+    import lib.sampling.sampling_utils as su
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.device = str(device)
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, device)
+    model.eval()
+    sampler = su.get_sampler(cfg)
+    return cfg, model, sampler
+
+
+def kernel_roofline(sampler, st, steps, batch):
+    """Mean duration of the fused tau-leap launch alone, HIP events on the launch stream, over the
+    same steps (logits recomputed outside the event bracket)."""
+    from ctdd import native
+    model = st.model
+    times = []
+    for i in steps:
+        t_ones = sampler._t_ones(st.t32, i, st.N, st.dev)
+        logits = model(st.x.long(), t_ones).float().contiguous()
+        h = float(np.float32(st.ts[i] - st.ts[i + 1]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st.x = native.tauleap_step(sampler.branch, sampler.logit_type, logits, st.x, st.qt0[i],
+                                   model.process.base_rate, st.betas[i], sampler.eps_ratio, h, st.flags, st.key,
+                                   10_000_000 + i)
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3)
+    dur = float(np.mean(times))
+    achieved = ALGO_BYTES_PER_SAMPLE_STEP * batch / dur / 1e9
+    return {"kernel": "ctdd tauleap_step (fused rates+draw+update)", "bound": "hbm", "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch}
+
+
+def cpu_baseline(model_gpu, cfg, batch, budget_s=20.0):
+    """The CPU oracle (restatement of the reference's CPU path, pinned by tests/golden) doing the
+    same tau-leaping step on the host cores: oracle U-Net forward + reverse rates + torch.poisson
+    + update.  Bounded sample: `batch` samples, as many steps as fit in ~budget_s."""
+    from oracle import ctmc_ops as ops, nets
+    from oracle.forward_process import ForwardProcess
+    # the GPU box gives one GPU's CPU share (16 cores) of a 256-thread host: use what we may run on
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    m = cfg.model
+    proc = ForwardProcess("gaussian", S, rate_sigma=m.rate_sigma, Q_sigma=m.Q_sigma, time_exp=m.time_exp, time_base=m.time_base)
+    sd = {k: v.detach().float().cpu() for k, v in model_gpu.state_dict().items() if isinstance(v, torch.Tensor)}
+    kw = dict(data_shape=list(cfg.data.shape), S=S, model_output=m.model_output, ch=m.ch, ch_mult=list(m.ch_mult),
+              n_res_blocks=m.num_res_blocks, num_heads=m.num_heads, x_min_max=list(m.data_min_max))
+    ts = ops.taul_time_grid(cfg.training.max_t, cfg.sampler.min_t, cfg.sampler.num_steps)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, S, (batch, D), generator=g)
+    done, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            i = done
+            t_ones = ts[i] * torch.ones((batch,))
+            h = ts[i] - ts[i + 1]
+            logits = nets.image_model_forward(sd, x, t_ones, **kw)
+            rr, _ = ops.reverse_rates_ctelbo(logits, x, proc.transition(t_ones), proc.rate(t_ones), cfg.sampler.eps_ratio)
+            jumps = torch.poisson(ops.zero_own_state(rr, x) * h)
+            x = ops.tauleap_apply(x, jumps, cfg.sampler.is_ordinal)
+            done += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or done >= 50:
+                break
+    return {"value": round(batch * done / el, 2), "unit": "sample-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{done} tau-leaping steps of {batch} samples (oracle U-Net fwd + rates + torch.poisson + update), {el:.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libctdd has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    cfg, model, sampler = build_model(dev)
+    sampler.seed = 42
+    sampler.rank_stream = rank              # distinct Philox key per rank; no data-path collective
+    K, W = a.steps, a.warmup
+    assert W + K + 1 <= sampler.num_steps
+    with torch.no_grad():
+        st = sampler.begin(model, a.batch)
+        for i in range(W):
+            sampler.advance(st, i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            sampler.advance(st, i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        roof = kernel_roofline(sampler, st, range(W + K, min(W + K + 20, sampler.num_steps - 1)), a.batch) if rank == 0 else None
+    if rank == 0:
+        value = a.batch * K * world / el
+        line = {
+            "metric": "tau-leaping sample-steps/s", "value": round(value, 2), "unit": "sample-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
+            "config": {"workload": "MNIST tauLDR U-Net TauL step (config_tauUnet_mnist: D=784, S=256, 1000-step grid)",
+                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "D": D, "S": S,
+                       "parallelism": f"sample-sharded x{world}, no collective in the loop"},
+            "dims_per_s": round(value * D, 1),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, cfg, a.cpu_batch)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

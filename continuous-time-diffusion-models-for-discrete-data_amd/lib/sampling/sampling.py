@@ -114,33 +114,50 @@ class TauL(_GridSampler):
         self.num_corrector_steps = s.num_corrector_steps
         self.is_ordinal = s.is_ordinal
 
-    def sample(self, model, N):
+    # The loop is split into begin / advance / finish so that a driver (bench.py, the multi-GPU
+    # sharder) can time or interleave exact sampler steps; sample() is their composition.
+    def begin(self, model, N):
         dev = torch.device(model.device)
-        key = self._key()
+        st = type("TauLState", (), {})()
+        st.model, st.N, st.dev, st.key = model, N, dev, self._key()
+        st.x = self._initial(model, N, st.key, self.cfg.model.Q_sigma)
+        st.ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
+        st.t32, st.qt0, st.betas = self._tables(model, st.ts[:-1])
+        st.changed = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
+        st.flags = native.STEP_ORDINAL if self.is_ordinal else 0
+        st.sub = 1 + max(int(self.num_corrector_steps), 0)
+        return st
+
+    def advance(self, st, i):
+        """Step i of the grid: network forward, fused reverse-rate/jump/update launch, correctors."""
+        model, N = st.model, st.N
+        t = st.ts[i]
+        h = float(np.float32(st.ts[i] - st.ts[i + 1]))
+        t_ones = self._t_ones(st.t32, i, N, st.dev)
+        q_i = st.qt0[i] if st.qt0 is not None else None
+        base_rate = model.process.base_rate
+        logits = model(st.x.long(), t_ones).float().contiguous()
+        st.x = native.tauleap_step(self.branch, self.logit_type, logits, st.x, q_i, base_rate, st.betas[i],
+                                   self.eps_ratio, h, st.flags, st.key, i * st.sub, changed=st.changed[i:i + 1])
+        if t <= self.corrector_entry_time:
+            for c in range(self.num_corrector_steps):
+                logits = model(st.x.long(), t_ones).float().contiguous()
+                st.x = native.tauleap_step(self.branch, self.logit_type, logits, st.x, q_i, base_rate, st.betas[i],
+                                           self.eps_ratio, h, st.flags | native.STEP_CORRECTOR, st.key,
+                                           i * st.sub + 1 + c)
+
+    def finish(self, st):
+        x = st.x
+        if self.loss_name in ("CTElbo", "NLL"):
+            x = self._final_argmax(st.model, x, st.N)
+        return x.cpu().numpy().astype(int), (st.changed.cpu().numpy() / st.N).tolist()
+
+    def sample(self, model, N):
         with torch.no_grad():
-            x = self._initial(model, N, key, self.cfg.model.Q_sigma)
-            ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
-            t32, qt0, betas = self._tables(model, ts[:-1])
-            changed = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
-            flags = native.STEP_ORDINAL if self.is_ordinal else 0
-            base_rate = model.process.base_rate
-            sub = 1 + max(int(self.num_corrector_steps), 0)
-            for i, t in enumerate(ts[:-1]):
-                h = float(np.float32(ts[i] - ts[i + 1]))
-                t_ones = self._t_ones(t32, i, N, dev)
-                q_i = qt0[i] if qt0 is not None else None
-                logits = model(x.long(), t_ones).float().contiguous()
-                x = native.tauleap_step(self.branch, self.logit_type, logits, x, q_i, base_rate, betas[i],
-                                        self.eps_ratio, h, flags, key, i * sub, changed=changed[i:i + 1])
-                if t <= self.corrector_entry_time:
-                    for c in range(self.num_corrector_steps):
-                        logits = model(x.long(), t_ones).float().contiguous()
-                        x = native.tauleap_step(self.branch, self.logit_type, logits, x, q_i, base_rate, betas[i],
-                                                self.eps_ratio, h, flags | native.STEP_CORRECTOR, key, i * sub + 1 + c)
-            if self.loss_name in ("CTElbo", "NLL"):
-                x = self._final_argmax(model, x, N)
-            change_dim = (changed.cpu().numpy() / N).tolist()
-            return x.cpu().numpy().astype(int), change_dim
+            st = self.begin(model, N)
+            for i in range(self.num_steps):
+                self.advance(st, i)
+            return self.finish(st)
 
 
 @sampling_utils.register_sampler

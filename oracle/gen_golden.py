@@ -17,6 +17,7 @@ sys.dont_write_bytecode = True
 sys.path[:0] = [os.path.join(HERE, "stubs"), "/root/reference/TAUnSDDM", ROOT]
 warnings.filterwarnings("ignore")
 
+import math  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from ml_collections import ConfigDict  # noqa: E402  (stub)
@@ -231,8 +232,55 @@ def gen_samplers():
     save("samplers", **arrs)
 
 
+# ------------------------------------------------------------------------------------ P8 (U-Net)
+def _tiny_unet_cfg(model_output, S, ch=16, image=8, channels=1):
+    c = base_cfg(S, image * image * channels)
+    c.data.image_size, c.data.shape = image, [channels, image, image]
+    c.model.update(dict(name="GaussianTargetRateImageX0PredEMAPaul", padding=False, ema_decay=0.999, ch=ch,
+                        num_res_blocks=1, ch_mult=[1, 2], input_channels=channels, data_min_max=[0, S - 1],
+                        dropout=0.1, fix_logistic=False, model_output=model_output, num_heads=2,
+                        attn_resolutions=[int(ch / 2)]))
+    return c
+
+
+def gen_unet():
+    """Tiny reference U-Net models (logits head and logistic head).  The reference initialises the
+    second conv of every ResBlock and the output conv at scale 1e-10 (logits ~ 0), so every
+    parameter is re-drawn N(0, 0.15/sqrt(fan_in)+) here to make all paths matter."""
+    import lib.models.models  # noqa: F401  registers
+    arrs = {}
+    for tag, mo, S, chn in (("logits", "logits", 16, 1), ("logistic", "logistic_pars", 16, 3)):
+        cfg = _tiny_unet_cfg(mo, S, channels=chn)
+        torch.manual_seed(11)
+        model = ref_mu.create_model(cfg, torch.device("cpu"))
+        g = torch.Generator().manual_seed(12)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if p.dim() > 1:
+                    fan_in = p[0].numel()
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(fan_in)))
+                elif "norm" in name and name.endswith("weight") or name.endswith("0.weight"):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        model.init_ema()          # eval() swaps the EMA shadow in: make it the re-drawn weights
+        model.eval()
+        B, D = 3, cfg.model.concat_dim
+        x = torch.randint(0, S, (B, D), generator=g)
+        t = torch.tensor([0.05, 0.5, 0.97])
+        with torch.no_grad():
+            logits = model(x, t)
+        sd = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+        arrs.update({f"{tag}__x": x, f"{tag}__t": t, f"{tag}__out": logits})
+        arrs.update({f"{tag}__sd__{k}": v for k, v in sd.items()})
+        arrs[f"{tag}__cfg"] = np.array(repr(dict(ch=cfg.model.ch, ch_mult=list(cfg.model.ch_mult), n_res_blocks=1,
+                                                 num_heads=2, x_min_max=[0, S - 1], model_output=mo, S=S,
+                                                 data_shape=list(cfg.data.shape))))
+    save("unet", **arrs)
+
+
 GROUPS = {"forward_process": gen_forward_process, "noising": gen_noising, "rates": gen_rates,
-          "samplers": gen_samplers}
+          "samplers": gen_samplers, "unet": gen_unet}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -154,3 +154,20 @@ def test_sampler_replay_exact(golden, tag):
     assert np.array_equal(out[0], g[f"{tag}__samples"]), "sampler output must replay exactly"
     for i, extra in enumerate(out[1:]):
         np.testing.assert_allclose(np.asarray(extra, dtype=np.float64), g[f"{tag}__aux{i}"], rtol=0, atol=1e-12, equal_nan=True)
+
+
+# ------------------------------------------------------------------ P8 (U-Net)
+def load_unet_case(g, tag):
+    cfg = ast.literal_eval(str(g[f"{tag}__cfg"]))
+    pre = f"{tag}__sd__"
+    sd = {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+    return cfg, sd, T(g[f"{tag}__x"]), T(g[f"{tag}__t"]), g[f"{tag}__out"]
+
+
+@pytest.mark.parametrize("tag", ["logits", "logistic"])
+def test_unet_oracle_matches_reference(golden, tag):
+    from oracle import nets
+    cfg, sd, x, t, out = load_unet_case(golden("unet"), tag)
+    got = nets.image_model_forward(sd, x, t, **cfg)
+    np.testing.assert_allclose(got.numpy(), out, rtol=0, atol=1e-4)       # BASELINE bar: logits within 1e-4 fp32
+    assert np.abs(out).max() > 1.0                                          # non-degenerate fixture
