@@ -73,15 +73,14 @@ def kernel_roofline(sampler, st, steps, batch):
         h = float(np.float32(st.ts[i] - st.ts[i + 1]))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        st.x = native.tauleap_step(sampler.branch, sampler.logit_type, logits, st.x, st.qt0[i],
-                                   model.process.base_rate, st.betas[i], sampler.eps_ratio, h, st.flags, st.key,
-                                   10_000_000 + i)
+        st.x = sampler._leap(model, logits, st.x, st.qt0[i], st.fast, i, st.betas[i], h, st.flags, st.key,
+                             10_000_000 + i)
         e1.record()
         e1.synchronize()
         times.append(e0.elapsed_time(e1) * 1e-3)
     dur = float(np.mean(times))
     achieved = ALGO_BYTES_PER_SAMPLE_STEP * batch / dur / 1e9
-    return {"kernel": "ctdd tauleap_step (fused rates+draw+update)", "bound": "hbm", "achieved": round(achieved, 2),
+    return {"kernel": "ctdd k_tauleap_s256 (fused softmax + split-bf16 MFMA contraction + Poisson draw + update)", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch}
 

@@ -4,8 +4,19 @@
 
 namespace ctdd {
 
-constexpr float POISSON_ICDF_MAX_LAMBDA = 12.0f;
+constexpr float POISSON_ICDF_MAX_LAMBDA = 12.0f;   // inverse-CDF search up to here, split above
 constexpr int POISSON_ICDF_KMAX = 64;
+// Row rule (superposition of independent Poisson processes, exact in distribution):
+//   Lambda = h * sum_s r_s <= SUPERPOSE_MAX_LAMBDA:  K ~ Poisson(Lambda) from uniform #0 of the row's
+//     stream, then K destinations ~ Categorical(r) by inverse CDF from uniforms #1.. ;
+//   above: the same one level down -- every sub-block b of 4 consecutive destinations draws
+//     K_b ~ Poisson(h * sum_{s in b} r_s) from uniform (b & 3) of Philox block DENSE_DRAW0 + (b >> 2)
+//     and, if K_b > 0, K_b picks among its 4 destinations from the private stream PICK_DRAW0 + 16 b
+//     (K_b for a rate > 12 is the sum of <= 64 equal parts from the stream SPLIT_DRAW0 + 16 b).
+constexpr float SUPERPOSE_MAX_LAMBDA = 2.0f;
+constexpr uint32_t DENSE_DRAW0 = 1024u;
+constexpr uint32_t SPLIT_DRAW0 = 8192u;
+constexpr uint32_t PICK_DRAW0 = 65536u;
 
 // Sequential-search inverse CDF of Poisson(lam), lam <= ~12.  Same operation order as
 // oracle/philox.py:poisson_icdf.
@@ -21,8 +32,7 @@ __device__ inline int poisson_icdf(float lam, float u) {
   return k;
 }
 
-// Poisson for any lam >= 0 from a private Philox stream (row, draws base..): inverse CDF for
-// small lam, Hoermann's PTRS transformed rejection (ACM TOMS 1993) above.
+// A private Philox stream: successive uniforms of (row, draw0, draw0+1, ...).
 struct PhiloxStream {
   uint64_t seed, offset, row;
   uint32_t draw;
@@ -41,26 +51,42 @@ struct PhiloxStream {
   }
 };
 
-__device__ inline int poisson_any(float lam, PhiloxStream& rng) {
-  if (!(lam > 0.0f)) return 0;  // also NaN / negative -> 0 (the reference raises ValueError there)
-  if (lam <= POISSON_ICDF_MAX_LAMBDA) return poisson_icdf(lam, rng.next());
-  if (!(lam < 1.0e9f)) return 1000000000;
-  const float slam = sqrtf(lam), loglam = logf(lam);
-  const float b = 0.931f + 2.53f * slam;
-  const float a = -0.059f + 0.02483f * b;
-  const float invalpha = 1.1239f + 1.1328f / (b - 3.4f);
-  const float vr = 0.9277f - 3.6224f / (b - 2.0f);
-  for (int it = 0; it < 32; ++it) {
-    const float U = rng.next() - 0.5f;
-    const float V = rng.next();
-    const float us = 0.5f - fabsf(U);
-    const float kf = floorf((2.0f * a / us + b) * U + lam + 0.43f);
-    if (us >= 0.07f && V <= vr) return (int)kf;
-    if (kf < 0.0f || (us < 0.013f && V > us)) continue;
-    if (logf(V) + logf(invalpha) - logf(a / (us * us) + b) <= -lam + kf * loglam - lgammaf(kf + 1.0f))
-      return (int)kf;
-  }
-  return (int)rintf(lam);
+// Poisson draw of one (sub-block) rate.  u = its uniform.  lam > 12 is split into n <= 64 equal
+// independent parts (a sum of Poissons is Poisson) drawn from the element's private stream; parts
+// that are still > 12 (lam > 768: every such draw saturates the state clamp) are taken at their
+// mean.  NaN / negative rates give 0 (the reference's torch.poisson raises there).
+__device__ inline int poisson_element(float lam, float u, uint64_t seed, uint64_t offset, uint64_t row, int s) {
+  if (!(lam > 0.0f)) return 0;
+  if (u + 2.0e-7f < 1.0f - lam) return 0;                 // u < 1-lam <= exp(-lam): certainly no jump
+  if (lam <= POISSON_ICDF_MAX_LAMBDA) return poisson_icdf(lam, u);
+  const int n = (int)fminf(ceilf(lam / POISSON_ICDF_MAX_LAMBDA), 64.0f);
+  const float lc = lam / (float)n;
+  if (!(lc <= POISSON_ICDF_MAX_LAMBDA)) return (int)fminf(rintf(lam), 1.0e9f);
+  PhiloxStream rs(seed, offset, row, SPLIT_DRAW0 + 16u * (uint32_t)s);   // s = sub-block index
+  int k = 0;
+  for (int i = 0; i < n; ++i) k += poisson_icdf(lc, rs.next());
+  return k;
 }
+
+// one sub-block of the dense regime: returns the number of jumps and adds sum_k (dest_k - base)
+// to *move.  r0..r3 = masked rates of destinations 4b..4b+3 (same units; `sh` turns them into
+// rate*h), u = the sub-block's uniform.
+__device__ inline int subblock_draw(float r0, float r1, float r2, float r3, float sh, float u, uint64_t seed,
+                                    uint64_t offset, uint64_t row, int b, int base, int nvalid, int* move) {
+  const float tot = (r0 + r1) + (r2 + r3);
+  const int K = poisson_element(sh * tot, u, seed, offset, row, b);
+  if (K > 0) {
+    PhiloxStream ps(seed, offset, row, PICK_DRAW0 + 16u * (uint32_t)b);
+    const float c0 = r0, c1 = r0 + r1, c2 = (r0 + r1) + r2;
+    for (int k = 0; k < K && k < 4096; ++k) {
+      const float v = ps.next() * tot;
+      int i = (v >= c0) + (v >= c1) + (v >= c2);
+      i = i < nvalid - 1 ? i : nvalid - 1;
+      *move += 4 * b + i - base;
+    }
+  }
+  return K;
+}
+
 
 }  // namespace ctdd

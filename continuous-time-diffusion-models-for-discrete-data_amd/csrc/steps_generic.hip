@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   const float Lam = T * a.h;
   const bool ordinal = a.flags & CTDD_STEP_ORDINAL;
   int jump = 0;
-  if (Lam > 0.0f && Lam <= POISSON_ICDF_MAX_LAMBDA) {
+  if (Lam > 0.0f && Lam <= SUPERPOSE_MAX_LAMBDA) {
     PhiloxStream rng(a.seed, a.offset, (uint64_t)rowc, 0u);   // identical in every lane of the row
     const int K = poisson_icdf(Lam, rng.next());
     if (K > 0 && (ordinal || K == 1)) {
@@ -341,17 +341,33 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
         jump += min(cnt, S - 1) - base;
       }
     }
-  } else if (Lam > POISSON_ICDF_MAX_LAMBDA) {
-    // dense regime: independent Poisson(rr_s*h) per element, private stream per element
+  } else if (Lam > SUPERPOSE_MAX_LAMBDA) {
+    // dense regime: per sub-block of 4 consecutive destinations (draw.hpp: subblock_draw).  The
+    // lane owning destination 4b (element s = li + k*G with s % 4 == 0) gathers its three
+    // neighbours by shuffle (G >= 4) or from its own slots (G < 4) and draws for the sub-block.
     int cnt = 0, jl = 0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int s = li + k * G;
-      if (s < S && rr[k] > 0.0f) {
-        PhiloxStream rs(a.seed, a.offset, (uint64_t)rowc, 1024u + 16u * (uint32_t)s);
-        const int ks = poisson_any(rr[k] * a.h, rs);
-        cnt += min(ks, 1 << 20);
-        jl += min(ks, 1 << 20) * (s - base);
+      float r1, r2, r3;
+      if (G >= 4) {
+        r1 = __shfl(rr[k], lane + 1, WAVE); r2 = __shfl(rr[k], lane + 2, WAVE); r3 = __shfl(rr[k], lane + 3, WAVE);
+      } else if (G == 2) {           // s, s+1 in lanes li, li+1 of slot k; s+2, s+3 in slot k+1
+        r1 = __shfl(rr[k], lane + 1, WAVE);
+        const float nx = k + 1 < EPT ? rr[k + 1] : 0.0f;
+        r2 = nx; r3 = __shfl(nx, lane + 1, WAVE);
+      } else {                       // G == 1: consecutive slots of this lane
+        r1 = k + 1 < EPT ? rr[k + 1] : 0.0f; r2 = k + 2 < EPT ? rr[k + 2] : 0.0f; r3 = k + 3 < EPT ? rr[k + 3] : 0.0f;
+      }
+      if ((s & 3) == 0 && s < S) {
+        if (s + 1 >= S) r1 = 0.0f;
+        if (s + 2 >= S) r2 = 0.0f;
+        if (s + 3 >= S) r3 = 0.0f;
+        const int b = s >> 2;
+        const u4 blk = philox_row(a.seed, a.offset, (uint64_t)rowc, DENSE_DRAW0 + (uint32_t)(b >> 2));
+        const uint32_t w = (b & 3) == 0 ? blk.x : (b & 3) == 1 ? blk.y : (b & 3) == 2 ? blk.z : blk.w;
+        cnt += min(subblock_draw(rr[k], r1, r2, r3, a.h, u01(w), a.seed, a.offset, (uint64_t)rowc, b, base,
+                                 min(4, S - s), &jl), 1 << 20);
       }
     }
     cnt = grp_sum_i(cnt, G);

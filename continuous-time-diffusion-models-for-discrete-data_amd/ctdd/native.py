@@ -44,6 +44,9 @@ _SIGS = {
     "ctdd_argmax": ([_P, _I, _I, _I, _P, _P], _I),
     "ctdd_initial_samples": ([_P, _U64, _U64, _I, _I, _I, _P, _P], _I),
     "ctdd_philox_uniform": ([_U64, _U64, _I64, _I, _P, _P], _I),
+    "ctdd_s256_step_table_bytes": ([], _I64),
+    "ctdd_s256_prepare": ([_P, _P, _F, _I, _P, _P, _P, _P], _I),
+    "ctdd_tauleap_step_s256": ([_P, _P, _P, _P, _P, _P, _F, _F, _U32, _U64, _U64, _I, _I, _P, _P, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -226,3 +229,41 @@ def philox_uniform(seed, offset, nrows, nblk, device):
     out = torch.empty((nrows, nblk * 4), dtype=f32, device=device)
     _check(load().ctdd_philox_uniform(seed, offset, nrows, nblk, _ptr(out), _stream()), "ctdd_philox_uniform")
     return out
+
+
+# ---------------------------------------------------------------- S = 256 fast path
+class S256Tables:
+    """Derived tables for the MFMA tau-leaping kernel: per-step blocks (resident for the whole
+    time grid) + the two per-model base-rate views."""
+
+    def __init__(self, qt0, base_rate, eps):
+        nT, S, _ = qt0.shape
+        if S != 256:
+            raise CtddError("S256Tables needs S == 256")
+        self.block = int(load().ctdd_s256_step_table_bytes())
+        dev = qt0.device
+        self.steps = torch.empty((nT, self.block), dtype=torch.uint8, device=dev)
+        self.RT0 = torch.empty((S, S), dtype=f32, device=dev)
+        self.R0 = torch.empty((S, S), dtype=f32, device=dev)
+        rc = load().ctdd_s256_prepare(_ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), float(eps), nT,
+                                      _ptr(self.steps), _ptr(self.RT0), _ptr(self.R0), _stream())
+        _check(rc, "ctdd_s256_prepare")
+
+    def step_ptr(self, i):
+        return self.steps.data_ptr() + i * self.block
+
+
+def tauleap_step_s256(logits, x, tables, i, beta, h, flags, seed, offset, x_base=None, out=None, changed=None,
+                      want_rates=False, want_x=True):
+    N, D, S = logits.shape
+    if S != 256:
+        raise CtddError("tauleap_step_s256 needs S == 256")
+    rates = torch.empty_like(logits) if want_rates else None
+    if want_x and out is None:
+        out = torch.empty((N, D), dtype=i32, device=x.device)
+    rc = load().ctdd_tauleap_step_s256(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"),
+                                       tables.step_ptr(i), _ptr(tables.RT0), _ptr(tables.R0), float(beta), float(h),
+                                       int(flags), seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
+                                       _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_tauleap_step_s256")
+    return (out, rates) if want_rates else out

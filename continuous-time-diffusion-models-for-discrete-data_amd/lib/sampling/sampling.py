@@ -97,6 +97,21 @@ class _GridSampler:
         t = torch.full((N,), float(np.float32(self.min_t)), device=x.device)
         return native.argmax(model(x.long(), t).float().contiguous())
 
+    def _fast_tables(self, model, qt0):
+        """S = 256 CT-ELBO branch: derived tables for the MFMA kernel (csrc/steps_s256.hip)."""
+        if self.S == 256 and self.branch == native.BRANCH_CTELBO and qt0 is not None \
+                and getattr(self.cfg.sampler, "fast_s256", True):
+            return native.S256Tables(qt0, model.process.base_rate, self.eps_ratio)
+        return None
+
+    def _leap(self, model, logits, x, q_i, fast, i, beta, h, flags, key, offset, x_base=None, changed=None):
+        """One fused reverse-rate / jump / update launch (MFMA path when prepared, else generic)."""
+        if fast is not None:
+            return native.tauleap_step_s256(logits, x, fast, i, beta, h, flags, key, offset, x_base=x_base,
+                                            changed=changed)
+        return native.tauleap_step(self.branch, self.logit_type, logits, x, q_i, model.process.base_rate, beta,
+                                   self.eps_ratio, h, flags, key, offset, x_base=x_base, changed=changed)
+
     @staticmethod
     def _t_ones(t32, i, N, device):
         return torch.full((N,), float(t32[i]), device=device, dtype=torch.float32)
@@ -123,6 +138,7 @@ class TauL(_GridSampler):
         st.x = self._initial(model, N, st.key, self.cfg.model.Q_sigma)
         st.ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
         st.t32, st.qt0, st.betas = self._tables(model, st.ts[:-1])
+        st.fast = self._fast_tables(model, st.qt0)
         st.changed = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
         st.flags = native.STEP_ORDINAL if self.is_ordinal else 0
         st.sub = 1 + max(int(self.num_corrector_steps), 0)
@@ -135,16 +151,14 @@ class TauL(_GridSampler):
         h = float(np.float32(st.ts[i] - st.ts[i + 1]))
         t_ones = self._t_ones(st.t32, i, N, st.dev)
         q_i = st.qt0[i] if st.qt0 is not None else None
-        base_rate = model.process.base_rate
         logits = model(st.x.long(), t_ones).float().contiguous()
-        st.x = native.tauleap_step(self.branch, self.logit_type, logits, st.x, q_i, base_rate, st.betas[i],
-                                   self.eps_ratio, h, st.flags, st.key, i * st.sub, changed=st.changed[i:i + 1])
+        st.x = self._leap(model, logits, st.x, q_i, st.fast, i, st.betas[i], h, st.flags, st.key, i * st.sub,
+                          changed=st.changed[i:i + 1])
         if t <= self.corrector_entry_time:
             for c in range(self.num_corrector_steps):
                 logits = model(st.x.long(), t_ones).float().contiguous()
-                st.x = native.tauleap_step(self.branch, self.logit_type, logits, st.x, q_i, base_rate, st.betas[i],
-                                           self.eps_ratio, h, st.flags | native.STEP_CORRECTOR, st.key,
-                                           i * st.sub + 1 + c)
+                st.x = self._leap(model, logits, st.x, q_i, st.fast, i, st.betas[i], h,
+                                  st.flags | native.STEP_CORRECTOR, st.key, i * st.sub + 1 + c)
 
     def finish(self, st):
         x = st.x
@@ -230,6 +244,7 @@ class MidPointTauL(_GridSampler):
             q_full = pr.tables(t32, want_qt0=True)[0] if need_q else None
             q_half = pr.tables(t32_half, want_qt0=True)[0] if need_q else None
             b_full, b_half = pr.beta(t32).tolist(), pr.beta(t32_half).tolist()
+            fast_half = self._fast_tables(model, q_half)
             cnt = torch.zeros(3, nst, dtype=torch.int32, device=dev)      # first / final / 1to2 changes
             flags = (native.STEP_ORDINAL if self.is_ordinal else 0) | native.STEP_COUNT_RAW
             hf = float(np.float32(h))
@@ -241,9 +256,8 @@ class MidPointTauL(_GridSampler):
                                                   q_full[i] if need_q else None, pr.base_rate, b_full[i],
                                                   self.eps_ratio, h)
                 logits_p = model(x_prime.long(), t_05).float().contiguous()
-                x_new = native.tauleap_step(self.branch, self.logit_type, logits_p, x,
-                                            q_half[i] if need_q else None, pr.base_rate, b_half[i], self.eps_ratio,
-                                            hf, flags, key, i, x_base=x_prime, changed=cnt[1, i:i + 1])
+                x_new = self._leap(model, logits_p, x, q_half[i] if need_q else None, fast_half, i, b_half[i], hf,
+                                   flags, key, i, x_base=x_prime, changed=cnt[1, i:i + 1])
                 cnt[0, i] = (x != x_prime).sum()
                 cnt[2, i] = (x_prime != x_new).sum()
                 x = x_new
@@ -274,12 +288,13 @@ class PCTauL(_GridSampler):
             ts = np.linspace(1.0, s.min_t + h0, s.num_steps)
             pr = model.process
             t32, qt0, betas = self._tables(model, ts)
+            fast = self._fast_tables(model, qt0)
             sub = 1 + max(int(s.num_corrector_steps), 0)
             for i, t in enumerate(ts[:-1]):
                 h = ts[i] - ts[i + 1]
                 logits = model(x.long(), self._t_ones(t32, i, N, dev)).float().contiguous()
-                x = native.tauleap_step(self.branch, "direct", logits, x, qt0[i], pr.base_rate, betas[i], s.eps_ratio,
-                                        float(np.float32(h)), native.STEP_ORDINAL, key, i * sub)
+                x = self._leap(model, logits, x, qt0[i], fast, i, betas[i], float(np.float32(h)), native.STEP_ORDINAL,
+                               key, i * sub)
                 if t <= s.corrector_entry_time:
                     tc = torch.tensor([t - h], dtype=torch.float64).to(torch.float32)
                     qc = pr.tables(tc, want_qt0=True)[0][0]

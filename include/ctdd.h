@@ -142,6 +142,24 @@ int ctdd_argmax(const float* logits, int N, int D, int S, int32_t* out_x, void* 
 int ctdd_initial_samples(const float* cdf, uint64_t seed, uint64_t offset, int N, int D, int S,
                          int32_t* out_x, void* stream);
 
+/* ---- S = 256 fast path (csrc/steps_s256.hip): the CT-ELBO-branch tau-leaping step on the matrix
+ * cores.  The contraction runs as split-precision bf16 MFMA (hi*hi + hi*lo + lo*hi, fp32
+ * accumulate; relative error of the non-negative sums < 3e-5, inside the 1e-4 parity bar).
+ * ctdd_s256_prepare builds, for nT steps, the per-step derived tables the kernel streams
+ * (1/(qt0[s0][x]+eps) and the bf16 hi/lo MFMA image of qt0) into caller-owned memory of
+ * nT * ctdd_s256_step_table_bytes() bytes, and the two per-model views of the base rate:
+ * RT0[x][s] = R[s][x], R0[x][s] = R[x][s], both with a zero diagonal ((256,256) f32 each). */
+int64_t ctdd_s256_step_table_bytes(void);
+int ctdd_s256_prepare(const float* qt0, const float* base_rate, float eps, int nT,
+                      void* out_step_tables, float* out_RT0, float* out_R0, void* stream);
+/* Same semantics as ctdd_tauleap_step(branch = CTELBO) for S = 256 (lib/sampling/sampling.py:
+ * 119-160, 165-221, 459-508).  step_tables points at THIS step's block.  out_rates (N,D,256),
+ * optional, receives the masked reverse rates (validation / unfused use); out_x may then be NULL. */
+int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, const int32_t* x_base,
+                           const void* step_tables, const float* RT0, const float* R0, float beta,
+                           float h, uint32_t flags, uint64_t seed, uint64_t offset, int N, int D,
+                           float* out_rates, int32_t* out_x, int32_t* out_changed, void* stream);
+
 /* test hook: the raw uniforms a kernel would see: out[row*4*nblk + 4*j + i]. */
 int ctdd_philox_uniform(uint64_t seed, uint64_t offset, int64_t nrows, int nblk, float* out,
                         void* stream);

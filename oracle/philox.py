@@ -51,22 +51,26 @@ def exp1(r):
     return (-np.log(u01(r).astype(np.float32))).astype(np.float32)
 
 
-def row_uniforms(rows, offset, seed, ndraw_blocks=1):
-    """uniforms[row, 4*ndraw_blocks] for flat row ids `rows` (uint64-able)."""
+def row_uniforms(rows, offset, seed, ndraw_blocks=1, draw0=0):
+    """uniforms[row, 4*ndraw_blocks] for flat row ids `rows` (uint64-able), blocks draw0.."""
     rows = np.asarray(rows, dtype=np.uint64)
     lo = (rows & MASK32).astype(np.uint32)
     hi = (rows >> np.uint64(32)).astype(np.uint32)
     k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     out = []
     for j in range(ndraw_blocks):
-        r = philox4x32_10(lo, hi, np.uint32(offset), np.uint32(j), k0, k1)
+        r = philox4x32_10(lo, hi, np.uint32(offset), np.uint32(draw0 + j), k0, k1)
         out.extend(u01(x) for x in r)
     return np.stack(out, axis=-1)
 
 
 # ------------------------------------------------------------------ draw rules of the kernels
-POISSON_ICDF_MAX_LAMBDA = 12.0   # rows with total rate*h above this take the per-element path
+POISSON_ICDF_MAX_LAMBDA = 12.0   # inverse-CDF search up to here, PTRS above
 POISSON_ICDF_KMAX = 64
+SUPERPOSE_MAX_LAMBDA = 2.0       # rows with total rate*h above this draw every destination independently
+DENSE_DRAW0 = 1024
+SPLIT_DRAW0 = 8192
+PICK_DRAW0 = 65536
 
 
 def poisson_icdf(lam, u):
@@ -105,41 +109,111 @@ def categorical_icdf(w, u):
 
 
 def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
-    """CPU replay of the kernels' jump draw (csrc/steps_generic.hip, MODE_TAULEAP):
+    """CPU replay of the kernels' jump draw (csrc/draw.hpp + steps_generic.hip / steps_s256.hip).
     rates (N,D,S) float32 reverse rates evaluated at x_base (default x); its own state is masked here.
-    K ~ Poisson(h*sum_s r_s) from uniform #0 of the row's stream; K destinations by inverse CDF
-    over r in s order from uniforms #1.. ; non-ordinal rows with K>1 stay put.
-    Rows with h*sum > POISSON_ICDF_MAX_LAMBDA use the per-element path and are flagged undecided.
+
+    Row rule: Lambda = h*sum_s r_s.
+      Lambda <= SUPERPOSE_MAX_LAMBDA: K ~ Poisson(Lambda) from uniform #0 of the row's stream, then
+        K destinations by inverse CDF over r in s order from uniforms #1.. ;
+      above: the same rule one level down: every sub-block b of 4 consecutive destinations draws
+        K_b ~ Poisson(h*sum_{s in b} r_s) from uniform (b&3) of Philox block DENSE_DRAW0 + (b>>2) and
+        K_b picks among its destinations from the stream PICK_DRAW0 + 16 b (a rate > 12 is the sum
+        of <= 64 equal parts from the stream SPLIT_DRAW0 + 16 b).
+    Non-ordinal rows with more than one jump stay put.
     Returns (x_new int64 (N,D), decided bool (N,D)) -- `decided` is False where a float
-    comparison sits within reassociation noise of a boundary (or on the dense path)."""
+    comparison sits within reassociation noise of a boundary."""
     r = np.array(rates, dtype=np.float32, copy=True)
     N, D, S = r.shape
     x = np.asarray(x).astype(np.int64)
     base = x if x_base is None else np.asarray(x_base).astype(np.int64)
     np.put_along_axis(r, base[..., None], 0.0, axis=-1)      # own state of the rate-state (x' if given)
     r = r.reshape(N * D, S)
+    h32 = np.float32(h)
     T = r.astype(np.float64).sum(-1)
-    lam = (T * np.float64(np.float32(h))).astype(np.float32)
+    lam = (T * np.float64(h32)).astype(np.float32)
     rows = np.arange(N * D, dtype=np.uint64)
-    nblk = 1 + (POISSON_ICDF_KMAX + 4) // 4
-    U = row_uniforms(rows, offset, seed, nblk)                     # (R, 4*nblk)
-    K, margin = poisson_icdf(lam, U[:, 0])
-    K = np.where(lam > 0, K, 0)
-    decided = (margin > 1e-5 * np.maximum(1.0, lam)) | (lam == 0)
-    dense = lam > POISSON_ICDF_MAX_LAMBDA
-    decided &= ~dense
     xf, bf = x.reshape(-1), base.reshape(-1)
     jump = np.zeros(N * D, dtype=np.int64)
-    for j in range(int(K[~dense].max()) if (~dense).any() else 0):
-        act = (K > j) & ~dense
-        if not act.any():
-            break
-        idx, mg = categorical_icdf(r[act], U[act, 1 + j])
-        jump[act] += idx - bf[act]
-        d = decided[act]
-        d &= mg > 1e-5
-        decided[act] = d
-    if not is_ordinal:
-        jump = np.where(K > 1, 0, jump)
+    decided = np.ones(N * D, dtype=bool)
+    decided &= np.abs(lam - SUPERPOSE_MAX_LAMBDA) > 1e-4       # regime choice itself must be clear
+    dense = lam > SUPERPOSE_MAX_LAMBDA
+    # ---- superposition regime
+    nblk = 1 + (POISSON_ICDF_KMAX + 4) // 4
+    sp = ~dense & (lam > 0)
+    if sp.any():
+        U = row_uniforms(rows[sp], offset, seed, nblk)
+        K, margin = poisson_icdf(lam[sp], U[:, 0])
+        dsp = margin > 1e-5
+        jsp = np.zeros(sp.sum(), dtype=np.int64)
+        rs, bs = r[sp], bf[sp]
+        for j in range(int(K.max()) if K.size else 0):
+            act = K > j
+            idx, mg = categorical_icdf(rs[act], U[act, 1 + j])
+            jsp[act] += idx - bs[act]
+            d = dsp[act]
+            d &= mg > 1e-5
+            dsp[act] = d
+        if not is_ordinal:
+            jsp = np.where(K > 1, 0, jsp)
+        jump[sp] = jsp
+        tmp = decided[sp]
+        tmp &= dsp
+        decided[sp] = tmp
+    # ---- dense regime: sub-blocks of 4 consecutive destinations (csrc/draw.hpp: subblock_draw)
+    if dense.any():
+        rd, rowsd, bd = r[dense], rows[dense], bf[dense]
+        nd = rd.shape[0]
+        nb = (S + 3) // 4
+        rp = np.zeros((nd, nb * 4), dtype=np.float32)
+        rp[:, :S] = rd
+        rp = rp.reshape(nd, nb, 4)
+        tot = ((rp[..., 0] + rp[..., 1]) + (rp[..., 2] + rp[..., 3])).astype(np.float32)
+        lam_b = (h32 * tot).astype(np.float32)
+        lo = (rowsd & MASK32).astype(np.uint32)
+        hi = (rowsd >> np.uint64(32)).astype(np.uint32)
+        k0, k1 = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+        U = np.empty((nd, nb), dtype=np.float32)
+        for blk in range((nb + 3) // 4):
+            w = philox4x32_10(lo, hi, np.uint32(offset), np.uint32(DENSE_DRAW0 + blk), k0, k1)
+            for c in range(4):
+                if 4 * blk + c < nb:
+                    U[:, 4 * blk + c] = u01(w[c])
+        Kb, margin = poisson_icdf(np.minimum(lam_b, np.float32(POISSON_ICDF_MAX_LAMBDA)), U)
+        Kb = np.where(lam_b > 0, Kb, 0)
+        margin = np.where(lam_b > 0, margin, 1.0)
+        dd = np.ones(nd, dtype=bool)
+        jl = np.zeros(nd, dtype=np.int64)
+        # rates above 12 are split into <= 64 equal parts from the sub-block's SPLIT stream
+        for ri, b in zip(*np.nonzero(lam_b > np.float32(POISSON_ICDF_MAX_LAMBDA))):
+            lam1 = lam_b[ri, b]
+            n = int(min(np.ceil(np.float32(lam1 / np.float32(POISSON_ICDF_MAX_LAMBDA))), 64.0))
+            lc = np.float32(lam1 / np.float32(n))
+            if not lc <= POISSON_ICDF_MAX_LAMBDA:
+                Kb[ri, b] = int(min(np.rint(lam1), 1.0e9))
+                continue
+            uu = row_uniforms(np.array([rowsd[ri]]), offset, seed, 16, draw0=SPLIT_DRAW0 + 16 * int(b))[0, :n]
+            kk, mg = poisson_icdf(np.full(n, lc, dtype=np.float32), uu)
+            Kb[ri, b] = int(kk.sum())
+            margin[ri, b] = mg.min()
+        dd &= margin.min(-1) > 1e-6
+        # picks inside the active sub-blocks
+        for ri, b in zip(*np.nonzero(Kb > 0)):
+            K = int(min(Kb[ri, b], 4096))
+            nblk = (K + 3) // 4
+            uu = row_uniforms(np.array([rowsd[ri]]), offset, seed, nblk, draw0=PICK_DRAW0 + 16 * int(b))[0, :K]
+            r4 = rp[ri, b]
+            c0, c1, c2 = r4[0], np.float32(r4[0] + r4[1]), np.float32(np.float32(r4[0] + r4[1]) + r4[2])
+            v = (uu * tot[ri, b]).astype(np.float32)
+            i = (v >= c0).astype(int) + (v >= c1).astype(int) + (v >= c2).astype(int)
+            i = np.minimum(i, min(4, S - 4 * b) - 1)
+            gap = np.min(np.abs(np.stack([v - c0, v - c1, v - c2])), axis=0) / max(float(tot[ri, b]), 1e-30)
+            if (gap < 1e-5).any():
+                dd[ri] = False
+            jl[ri] += int(np.sum(4 * b + i - bd[ri]))
+        cnt = Kb.sum(-1)
+        jump[dense] = jl if is_ordinal else np.where(cnt <= 1, jl, 0)
+        tmp = decided[dense]
+        tmp &= dd
+        decided[dense] = tmp
     xn = np.clip(xf + jump, 0, S - 1)
     return xn.reshape(N, D), decided.reshape(N, D)

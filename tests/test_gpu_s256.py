@@ -1,0 +1,105 @@
+"""GPU: the S=256 MFMA fast path (csrc/steps_s256.hip) against the oracle and against the generic
+exact-fp32 kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ctmc_ops as ops
+from oracle import philox as oph
+from oracle.forward_process import ForwardProcess
+
+S = 256
+
+
+@pytest.fixture(scope="module")
+def env():
+    from ctdd import native
+    from ctdd.process import DeviceForwardProcess
+    p = dict(rate_sigma=6.0, Q_sigma=512.0, time_exp=100.0, time_base=3.0)
+    return native, DeviceForwardProcess("gaussian", S, "cuda", **p), ForwardProcess("gaussian", S, **p)
+
+
+def _case(N, D, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(N, D, S, generator=g) * scale, torch.randint(0, S, (N, D), generator=g)
+
+
+@pytest.mark.parametrize("t,scale,N,D", [(0.5, 1.0, 3, 100), (0.05, 4.0, 2, 131), (0.97, 2.0, 1, 784), (0.3, 8.0, 5, 64)])
+def test_rates_match_oracle(env, t, scale, N, D):
+    """Masked reverse rates from the split-bf16 MFMA path: rtol 1e-4 vs the oracle (the stated
+    parity bar for rates), and the measured error vs float64 stays below 3e-5."""
+    native, pr, op = env
+    logits, x = _case(N, D, 1, scale)
+    tt = torch.tensor([t])
+    # same table on both sides: the reference zeroes q_{t|0} entries below 1e-8, so an entry that
+    # lands on the other side of that threshold in a different summation order changes
+    # 1/(q+eps) by an order of magnitude -- a property of the algorithm, tested in K1's own test
+    qt0 = op.transition(tt).cuda()
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9)
+    beta = float(pr.beta(tt)[0])
+    _, rates = native.tauleap_step_s256(logits.cuda().contiguous(), x.to(torch.int32).cuda(), tabs, 0, beta, 1e-3, 1, 1, 0,
+                                        want_rates=True)
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    ref = ops.zero_own_state(ops.reverse_rates_ctelbo(logits, x, q, r, 1e-9)[0], x)
+    got = rates.cpu()
+    # rates below 1e-25 sit in / next to the fp32 denormal range (forward rates exp(-k^2/36) far
+    # from x): the reference's own fp32 value there has no relative accuracy, and such a rate
+    # never produces a jump, so they are compared absolutely.
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-25)
+    # the contraction itself (ratio = rates / forward rate) against float64 from the same fp32 table
+    p = torch.softmax(logits.double(), -1)
+    q64 = qt0[0].cpu().double()
+    truth = (p / (q64.t()[x] + 1e-9)) @ q64
+    fwd = ops.zero_own_state(r[0].t()[x], x).double()
+    ok = fwd > 1e-20
+    rel = ((got.double() / fwd.clamp_min(1e-300) - truth).abs() / truth)[ok]
+    assert rel.max().item() < 3e-5, rel.max().item()
+
+
+@pytest.mark.parametrize("flags", [1, 0, 3])
+def test_fused_step_matches_generic_and_replay(env, flags):
+    native, pr, op = env
+    N, D = 4, 300
+    logits, x = _case(N, D, 5, 2.0)
+    tt = torch.tensor([0.4])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = ops.reverse_rates_ctelbo(logits, x, q, r, 1e-9)[0]
+    if flags & 2:
+        rr = rr + ops.transpose_forward_rates(r, x)
+    h = float(1.0 / ops.zero_own_state(rr, x).sum(-1).median())
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9)
+    dl, dx = logits.cuda().contiguous(), x.to(torch.int32).cuda()
+    changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 77, 3, changed=changed).cpu().long()
+    gen = native.tauleap_step(native.BRANCH_CTELBO, "direct", dl, dx, qt0[0], pr.base_rate, beta, 1e-9, h, flags, 77, 3).cpu().long()
+    assert (out != gen).float().mean().item() < 3e-3          # same Philox stream; only fp near-ties differ
+    ref, decided = oph.tauleap_draw_replay(rr.numpy(), x.numpy(), h, bool(flags & 1), 77, 3)
+    dec = torch.from_numpy(decided)
+    assert dec.float().mean() > 0.6
+    assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 3e-3
+    assert int(changed.item()) == int((out != x).sum())
+    assert (out != x).float().mean() > 0.05
+
+
+def test_midpoint_base_and_ragged_tail(env):
+    """x_base semantics (rates at x', move added to x) and a row count that is not a tile multiple."""
+    native, pr, op = env
+    N, D = 1, 131
+    logits, x = _case(N, D, 9, 2.0)
+    xb = (x + torch.randint(-3, 4, x.shape)).clamp(0, S - 1)
+    tt = torch.tensor([0.6])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9)
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = ops.reverse_rates_ctelbo(logits, xb, q, r, 1e-9)[0]
+    h = float(1.0 / ops.zero_own_state(rr, xb).sum(-1).median())
+    out = native.tauleap_step_s256(logits.cuda().contiguous(), x.to(torch.int32).cuda(), tabs, 0, beta, h, 0, 5, 1,
+                                   x_base=xb.to(torch.int32).cuda()).cpu().long()
+    ref, decided = oph.tauleap_draw_replay(rr.numpy(), x.numpy(), h, False, 5, 1, x_base=xb.numpy())
+    dec = torch.from_numpy(decided)
+    assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 1e-2 and dec.float().mean() > 0.5
