@@ -1,0 +1,418 @@
+"""Hand-written HIP inference engine for the tauLDR U-Net (lib/networks/unet.py; reference
+TAUnSDDM/lib/networks/unet.py:303-459 + lib/models/models.py:225-292).
+
+The engine walks the module tree of a built model once, packs every weight into the layouts the
+kernels of csrc/unet_kernels.hip stream (implicit-GEMM [N][K] bf16 hi/lo, K = segment -> tap ->
+channel), allocates all intermediate NHWC tensors for a given batch size, and records the forward
+as a flat list of pre-bound launches.  The list is captured into a HIP graph (torch.cuda.CUDAGraph
+is the capture API; every node is one of our kernels) and replayed per call, so a sampler step costs
+one graph launch instead of ~150 Python-side launches.
+
+precision = "bf16":  bf16 activations / weights on v_mfma_f32_32x32x16_bf16, fp32 accumulate (the
+                     BASELINE config's dtype; throughput path)
+precision = "fp32":  fp32 activations / weights on the exact-fp32 v_mfma_f32_32x32x2_f32 -- the path
+                     the 1e-4 logit parity test runs.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import native
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+SEG_3x3, SEG_1x1, SEG_3x3_S2, SEG_3x3_UP = 0, 1, 2, 3
+
+
+class _Seg(C.Structure):
+    _fields_ = [("hi", _P), ("f32", _P), ("C", _I), ("kind", _I)]
+
+
+class _ConvArgs(C.Structure):
+    _fields_ = [("seg", _Seg * 3), ("nseg", _I), ("w_hi", _P), ("w_f32", _P), ("B", _I), ("H", _I), ("W", _I),
+                ("Hin", _I), ("Win", _I), ("N", _I), ("Ktot", _I), ("bias", _P), ("tbias", _P), ("tb_stride", _I),
+                ("res_f32", _P), ("res_bf16", _P), ("out_f32", _P), ("out_hi", _P), ("stats", _P), ("logits_C", _I)]
+
+
+class _FirstArgs(C.Structure):
+    _fields_ = [("x64", _P), ("x32", _P), ("lo", _F), ("hi", _F), ("w", _P), ("bias", _P), ("B", _I), ("Cin", _I),
+                ("H", _I), ("W", _I), ("Cout", _I), ("out_f32", _P), ("out_hi", _P), ("stats", _P), ("x0_f32", _P)]
+
+
+class _GnArgs(C.Structure):
+    _fields_ = [("s1_f32", _P), ("s1_bf16", _P), ("st1", _P), ("C1", _I), ("s2_f32", _P), ("s2_bf16", _P), ("st2", _P),
+                ("C2", _I), ("gamma", _P), ("beta", _P), ("B", _I), ("HW", _I), ("G", _I), ("eps", _F), ("swish", _I),
+                ("out_hi", _P), ("out_f32", _P)]
+
+
+class _TimeArgs(C.Structure):
+    _fields_ = [("t", _P), ("B", _I), ("ch", _I), ("tdim", _I), ("w1", _P), ("b1", _P), ("w2", _P), ("b2", _P),
+                ("act", _P)]
+
+
+class _AttnArgs(C.Structure):
+    _fields_ = [("qkv", _P), ("B", _I), ("T", _I), ("C", _I), ("heads", _I), ("out_hi", _P), ("out_f32", _P)]
+
+
+class _LogisticArgs(C.Structure):
+    _fields_ = [("net", _P), ("x0", _P), ("B", _I), ("C", _I), ("HW", _I), ("S", _I), ("fix", _I), ("out", _P)]
+
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    lib = native.load()
+    if not _sigs_done:
+        for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_first_conv", [_P, _P]),
+                           ("ctdd_unet_gn_apply", [_P, _P]), ("ctdd_unet_channel_stats", [_P, _I, _I, _I, _P, _P]),
+                           ("ctdd_unet_time", [_P, _P, _P, _I, _P, _P]), ("ctdd_unet_attention", [_P, _P]),
+                           ("ctdd_unet_logistic_head", [_P, _P])):
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argt, _I
+        _sigs_done = True
+    return lib
+
+
+def supports(model):
+    """The engine covers the reference's image U-Net wrapper without padding."""
+    net = getattr(model, "net", None)
+    return (net is not None and net.__class__.__name__ == "UNet" and not model.padding
+            and model.cfg.model.model_output in ("logits", "logistic_pars"))
+
+
+class _Tensor:
+    """NHWC activation [B*H*W][C]: bf16 (`hi`) in bf16 mode, fp32 (`f32`) in fp32 mode, plus the offset
+    of its per-(b, channel) statistics in the plan's pool."""
+
+    def __init__(self, eng, B, H, W, Cn, stats=True):
+        dev, M = eng.dev, B * H * W
+        self.B, self.H, self.W, self.C = B, H, W, Cn
+        self.f32 = torch.empty((M, Cn), dtype=torch.float32, device=dev) if eng.precise else None
+        self.hi = None if eng.precise else torch.empty((M, Cn), dtype=torch.bfloat16, device=dev)
+        self.stats = eng.alloc_stats(B * Cn * 2) if stats else None
+        eng._live.append(self)           # raw pointers are baked into the plan: keep every buffer alive
+
+
+class UNetEngine:
+    def __init__(self, model, precision=None):
+        self.model = model
+        self.net = model.net
+        self.cfg = model.cfg
+        self.dev = next(self.net.parameters()).device
+        if self.dev.type != "cuda":
+            raise native.CtddError("UNetEngine needs the model on a GPU")
+        self.precision = precision or getattr(self.cfg.model, "engine_precision", "bf16")
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError(f"unknown engine precision {self.precision}")
+        self.precise = self.precision == "fp32"
+        self._plans = {}
+        self._wver = None
+        self._packed = None
+
+    # ------------------------------------------------------------------ weights
+    def _weights_version(self):
+        return sum(p._version for p in self.net.parameters()) + 7919 * getattr(self.model, "_weights_version", 0)
+
+    def _pack(self, w2d):
+        """[N][K] weights in the mode's element type: (bf16 | None, fp32 | None)."""
+        w = w2d.detach().float().contiguous()
+        return (None, w) if self.precise else (w.to(torch.bfloat16).contiguous(), None)
+
+    @staticmethod
+    def _conv_w(weight, splits):
+        """torch conv weight [N][Cin][3][3] -> [N][K], K = segment -> tap -> channel."""
+        parts, c0 = [], 0
+        for cs in splits:
+            parts.append(weight[:, c0:c0 + cs].permute(0, 2, 3, 1).reshape(weight.shape[0], 9 * cs))
+            c0 += cs
+        return torch.cat(parts, dim=1)
+
+    # ------------------------------------------------------------------ plan construction
+    def alloc_stats(self, n):
+        off = self._stats_off
+        self._stats_off += n
+        return off
+
+    def _build(self, B, x_dtype):
+        net, m = self.net, self.cfg.model
+        lib = _lib()
+        dev = self.dev
+        Cin, H0, W0 = self.cfg.data.shape
+        ch, S = net.channel, net.S
+        plan, keep = [], []
+        self._stats_off = 0
+        self._live = keep
+        st = type("Plan", (), {})()
+        st.B = B
+        st.x_in = torch.zeros((B, Cin, H0, W0), dtype=x_dtype, device=dev)
+        st.t_in = torch.zeros((B,), dtype=torch.float32, device=dev)
+        stream = lambda: torch.cuda.current_stream().cuda_stream
+
+        def ptr(t):
+            return None if t is None else t.data_ptr()
+
+        def launch(fn, *args):
+            def run():
+                rc = fn(*args, stream())
+                if rc != 0:
+                    raise native.CtddError(f"{fn.__name__} failed ({rc}): {lib.ctdd_last_error().decode()}")
+            plan.append(run)
+
+        bks = (32, 16) if self.precise else (96, 64, 32, 16)      # fp32 tiles: K = 32 keeps 4 workgroups per CU
+
+        def pick_bk(cs):
+            for bk in bks:
+                if all(c % bk == 0 for c in cs):
+                    return bk
+            raise native.CtddError(f"no K tile divides channel counts {cs}")
+
+        def pick_bnt(N, bk):
+            if bk == 16:
+                return 1
+            if N % 96 == 0 and bk in (96, 32):
+                return 3
+            if N % 128 == 0:
+                return 4
+            if N % 64 == 0 and bk == 64:
+                return 2
+            return 1
+
+        stats_views = []          # (tensor, offset) resolved after the pool exists
+
+        def conv(segs, w2d, bias, N, Hout, Wout, Hin, Win, out, tb=None, res=None, logits_C=0, out_f32_tensor=None):
+            """segs: list of (_Tensor, channels, kind)."""
+            a = _ConvArgs()
+            a.nseg = len(segs)
+            for i, (src, cs, kind) in enumerate(segs):
+                a.seg[i].hi, a.seg[i].f32, a.seg[i].C, a.seg[i].kind = ptr(src.hi), ptr(src.f32), cs, kind
+            whi, wf = self._pack(w2d)
+            keep.extend([whi, wf, bias])
+            a.w_hi, a.w_f32 = ptr(whi), ptr(wf)
+            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = B, Hout, Wout, Hin, Win, N, w2d.shape[1]
+            a.bias = ptr(bias)
+            if tb is not None:
+                a.tbias, a.tb_stride = tb
+            if res is not None:
+                if self.precise:
+                    a.res_f32 = ptr(res.f32)
+                else:
+                    a.res_bf16 = ptr(res.hi)
+            if out_f32_tensor is not None:
+                a.out_f32 = ptr(out_f32_tensor)
+            elif out is not None:
+                a.out_f32, a.out_hi = ptr(out.f32), ptr(out.hi)
+                if out.stats is not None:
+                    stats_views.append((a, out.stats))
+            a.logits_C = logits_C
+            bk = pick_bk([s[1] for s in segs])
+            bnt = pick_bnt(N, bk)
+            keep.append(a)
+            launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise))
+
+        def gn_apply(srcs, norm, swish, eps, HW):
+            """srcs: one or two _Tensor; returns activated planes tensor."""
+            Ct = sum(s.C for s in srcs)
+            out = _Tensor(self, B, srcs[0].H, srcs[0].W, Ct, stats=False)
+            a = _GnArgs()
+            s1 = srcs[0]
+            a.s1_f32, a.s1_bf16, a.C1 = (ptr(s1.f32), None, s1.C) if self.precise else (None, ptr(s1.hi), s1.C)
+            stats_views.append((a, s1.stats, "st1"))
+            if len(srcs) == 2:
+                s2 = srcs[1]
+                a.s2_f32, a.s2_bf16, a.C2 = (ptr(s2.f32), None, s2.C) if self.precise else (None, ptr(s2.hi), s2.C)
+                stats_views.append((a, s2.stats, "st2"))
+            g, b_ = norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous()
+            keep.extend([g, b_, a, out])
+            a.gamma, a.beta = ptr(g), ptr(b_)
+            a.B, a.HW, a.G, a.eps, a.swish = B, HW, norm.num_groups, eps, int(swish)
+            a.out_hi, a.out_f32 = ptr(out.hi), ptr(out.f32)
+            launch(lib.ctdd_unet_gn_apply, C.byref(a))
+            return out
+
+        # ---- time embedding + all ResBlock projections in two launches
+        resblocks = [mod.resblocks for mod in list(net.down) + list(net.mid) + list(net.up) if hasattr(mod, "resblocks")]
+        tdim = ch * 4
+        pw = torch.cat([rb.time[1].weight.detach().float() for rb in resblocks], 0).contiguous()
+        pb = torch.cat([rb.time[1].bias.detach().float() for rb in resblocks], 0).contiguous()
+        Ntot = pw.shape[0]
+        st.tact = torch.empty((B, tdim), dtype=torch.float32, device=dev)
+        st.tproj = torch.empty((B, Ntot), dtype=torch.float32, device=dev)
+        ta = _TimeArgs()
+        tw = [net.time[1].weight, net.time[1].bias, net.time[3].weight, net.time[3].bias]
+        tw = [w.detach().float().contiguous() for w in tw]
+        ta.t, ta.B, ta.ch, ta.tdim = ptr(st.t_in), B, ch, tdim
+        ta.w1, ta.b1, ta.w2, ta.b2, ta.act = ptr(tw[0]), ptr(tw[1]), ptr(tw[2]), ptr(tw[3]), ptr(st.tact)
+        keep.extend(tw + [pw, pb, ta])
+        launch(lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
+        toff = {}
+        o = 0
+        for rb in resblocks:
+            toff[id(rb)] = o
+            o += rb.time[1].weight.shape[0]
+
+        # ---- first conv
+        c0 = net.down[0]
+        cur = _Tensor(self, B, H0, W0, ch)
+        fa = _FirstArgs()
+        if x_dtype == torch.int64:
+            fa.x64 = ptr(st.x_in)
+        else:
+            fa.x32 = ptr(st.x_in)
+        fa.lo, fa.hi = float(net.x_min_max[0]), float(net.x_min_max[1])
+        w0, b0 = c0.weight.detach().float().contiguous(), c0.bias.detach().float().contiguous()
+        fa.w, fa.bias, fa.B, fa.Cin, fa.H, fa.W, fa.Cout = ptr(w0), ptr(b0), B, Cin, H0, W0, ch
+        fa.out_f32, fa.out_hi = ptr(cur.f32), ptr(cur.hi)
+        logistic = m.model_output == "logistic_pars"
+        if logistic:
+            st.x0 = torch.empty((B, Cin, H0, W0), dtype=torch.float32, device=dev)
+            fa.x0_f32 = ptr(st.x0)
+        stats_views.append((fa, cur.stats))
+        keep.extend([w0, b0, fa])
+        launch(lib.ctdd_unet_first_conv, C.byref(fa))
+
+        def resblock(rb, srcs):
+            """srcs: list of 1-2 tensors forming the (virtual) channel concatenation."""
+            Hc, Wc = srcs[0].H, srcs[0].W
+            cs = [s.C for s in srcs]
+            cout = rb.conv1.weight.shape[0]
+            a1 = gn_apply(srcs, rb.norm1, True, rb.norm1.eps, Hc * Wc)
+            h = _Tensor(self, B, Hc, Wc, cout)
+            b1 = rb.conv1.bias.detach().float().contiguous()
+            conv([(a1, a1.C, SEG_3x3)], self._conv_w(rb.conv1.weight.detach().float(), [a1.C]), b1, cout, Hc, Wc,
+                 Hc, Wc, h, tb=(st.tproj.data_ptr() + 4 * toff[id(rb)], Ntot))
+            a2 = gn_apply([h], rb.norm2, True, rb.norm2.eps, Hc * Wc)
+            y = _Tensor(self, B, Hc, Wc, cout)
+            w2 = self._conv_w(rb.conv2.weight.detach().float(), [cout])
+            bias2 = rb.conv2.bias.detach().float()
+            segs = [(a2, cout, SEG_3x3)]
+            res = None
+            if rb.skip is not None:
+                sw, c_ = rb.skip.weight.detach().float(), 0
+                for s_ in srcs:                       # linear skip folded in as 1x1 K-segments on the raw input
+                    segs.append((s_, s_.C, SEG_1x1))
+                    w2 = torch.cat([w2, sw[:, c_:c_ + s_.C]], dim=1)
+                    c_ += s_.C
+                bias2 = bias2 + rb.skip.bias.detach().float()
+            else:
+                res = srcs[0]
+            conv(segs, w2.contiguous(), bias2.contiguous(), cout, Hc, Wc, Hc, Wc, y, res=res)
+            return y
+
+        def attention(att, x):
+            T = x.H * x.W
+            an = gn_apply([x], att.norm, False, att.norm.eps, T)
+            Cx = x.C
+            qkv = torch.empty((B * T, 3 * Cx), dtype=torch.float32, device=dev)
+            keep.append(qkv)
+            conv([(an, Cx, SEG_1x1)], att.qkv.weight.detach().float().reshape(3 * Cx, Cx).contiguous(),
+                 att.qkv.bias.detach().float().contiguous(), 3 * Cx, x.H, x.W, x.H, x.W, None, out_f32_tensor=qkv)
+            ao = _Tensor(self, B, x.H, x.W, Cx, stats=False)
+            aa = _AttnArgs()
+            aa.qkv, aa.B, aa.T, aa.C, aa.heads, aa.out_hi, aa.out_f32 = ptr(qkv), B, T, Cx, att.num_heads, ptr(ao.hi), ptr(ao.f32)
+            keep.extend([aa, ao])
+            launch(lib.ctdd_unet_attention, C.byref(aa))
+            y = _Tensor(self, B, x.H, x.W, Cx)
+            conv([(ao, Cx, SEG_1x1)], att.proj_out.weight.detach().float().reshape(Cx, Cx).contiguous(),
+                 att.proj_out.bias.detach().float().contiguous(), Cx, x.H, x.W, x.H, x.W, y, res=x)
+            return y
+
+        feats = [cur]
+        for layer in list(net.down)[1:]:
+            if hasattr(layer, "resblocks"):
+                cur = resblock(layer.resblocks, [cur])
+                if layer.attention is not None:
+                    cur = attention(layer.attention, cur)
+            else:                                      # Downsample: stride-2 conv, pad right/bottom by one
+                cv = layer.downsample[0]
+                Ho, Wo = (cur.H + 1 - 3) // 2 + 1, (cur.W + 1 - 3) // 2 + 1
+                y = _Tensor(self, B, Ho, Wo, cur.C)
+                conv([(cur, cur.C, SEG_3x3_S2)], self._conv_w(cv.weight.detach().float(), [cur.C]),
+                     cv.bias.detach().float().contiguous(), cur.C, Ho, Wo, cur.H, cur.W, y)
+                cur = y
+            feats.append(cur)
+        for layer in net.mid:
+            cur = resblock(layer.resblocks, [cur])
+            if layer.attention is not None:
+                cur = attention(layer.attention, cur)
+        for layer in net.up:
+            if hasattr(layer, "resblocks"):
+                cur = resblock(layer.resblocks, [cur, feats.pop()])
+                if layer.attention is not None:
+                    cur = attention(layer.attention, cur)
+            else:                                      # Upsample: nearest x2 folded into the conv's addressing
+                cv = layer[1]
+                y = _Tensor(self, B, cur.H * 2, cur.W * 2, cur.C)
+                conv([(cur, cur.C, SEG_3x3_UP)], self._conv_w(cv.weight.detach().float(), [cur.C]),
+                     cv.bias.detach().float().contiguous(), cur.C, cur.H * 2, cur.W * 2, cur.H, cur.W, y)
+                cur = y
+        ao = gn_apply([cur], net.out[0], True, net.out[0].eps, cur.H * cur.W)
+        oc = net.out[2]
+        n_out = oc.weight.shape[0]
+        D = Cin * H0 * W0
+        if logistic:
+            st.net_out = torch.empty((B * H0 * W0, n_out), dtype=torch.float32, device=dev)
+            conv([(ao, ao.C, SEG_3x3)], self._conv_w(oc.weight.detach().float(), [ao.C]),
+                 oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.net_out)
+            st.logits = torch.empty((B, D, S), dtype=torch.float32, device=dev)
+            la = _LogisticArgs()
+            la.net, la.x0, la.B, la.C, la.HW, la.S, la.fix, la.out = (ptr(st.net_out), ptr(st.x0), B, Cin, H0 * W0, S,
+                                                                     int(bool(m.fix_logistic)), ptr(st.logits))
+            keep.append(la)
+            launch(lib.ctdd_unet_logistic_head, C.byref(la))
+        else:
+            st.logits = torch.empty((B, D, S), dtype=torch.float32, device=dev)
+            conv([(ao, ao.C, SEG_3x3)], self._conv_w(oc.weight.detach().float(), [ao.C]),
+                 oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.logits,
+                 logits_C=Cin)
+
+        # ---- the per-(b, channel) statistics pool: one buffer, zeroed once per forward
+        st.stats = torch.zeros((max(self._stats_off, 1),), dtype=torch.float64, device=dev)
+        base = st.stats.data_ptr()
+        for item in stats_views:
+            if len(item) == 2:
+                item[0].stats = base + 8 * item[1]
+            else:
+                setattr(item[0], item[2], base + 8 * item[1])
+        st.plan, st.keep, st.graph = plan, keep, None
+        return st
+
+    # ------------------------------------------------------------------ execution
+    def _run_plan(self, st):
+        st.stats.zero_()
+        for step in st.plan:
+            step()
+
+    def __call__(self, x, times):
+        B = x.shape[0]
+        key = (B, x.dtype)
+        ver = self._weights_version()
+        if ver != self._wver:                     # weights changed (optimizer step, EMA swap): re-pack
+            self._plans.clear()
+            self._wver = ver
+        st = self._plans.get(key)
+        if st is None:
+            if x.dtype not in (torch.int64, torch.int32):
+                raise native.CtddError(f"UNetEngine expects integer states, got {x.dtype}")
+            st = self._plans[key] = self._build(B, x.dtype)
+            st.x_in.copy_(x.reshape(st.x_in.shape))
+            st.t_in.copy_(times.float())
+            self._run_plan(st)                    # eager warm-up (also sets the LDS attributes)
+            torch.cuda.synchronize()
+            if getattr(self.cfg.model, "engine_graph", True):
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._run_plan(st)
+                    st.graph = g
+                except Exception:                 # capture unsupported: keep eager launches
+                    st.graph = None
+                    torch.cuda.synchronize()
+        st.x_in.copy_(x.reshape(st.x_in.shape))
+        st.t_in.copy_(times.float())
+        if st.graph is not None:
+            st.graph.replay()
+        else:
+            self._run_plan(st)
+        return st.logits

@@ -2,10 +2,10 @@
 
 The module tree reproduces the reference's parameter names (`time.1`, `down.N.resblocks.conv1`,
 `down.N.downsample.0`, `mid.0.attention.qkv`, `up.N.1`, `out.2`, ...) so its checkpoints load
-unchanged, but the network is described once as a flat *plan* (`self.plan`, a list of op
-records).  The plan is what both executors walk:
+unchanged.  Two executors read this tree:
   * `forward()` -- differentiable device ops, used for training (autograd);
-  * `ctdd.unet_engine` -- the hand-written HIP inference engine used by the samplers.
+  * `ctdd.unet_engine.UNetEngine` -- the hand-written HIP inference engine (csrc/unet_kernels.hip)
+    that the samplers run under `torch.no_grad()` in eval mode.
 """
 import math
 

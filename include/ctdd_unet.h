@@ -1,0 +1,68 @@
+/* ctdd_unet.h -- C ABI of the U-Net inference kernels in libctdd.so (csrc/unet_kernels.hip).
+ *
+ * These entry points replace the forward pass of the reference's score network on the sampling
+ * path: TAUnSDDM/lib/networks/unet.py:419-459 (UNet.forward) with its blocks (ResBlock 100-140,
+ * Downsample/Upsample 79-97, SelfAttention/QKVAttention 152-200, TimeEmbedding 223-241) and the
+ * logistic head of TAUnSDDM/lib/models/models.py:249-283.  Same conventions as ctdd.h: caller-
+ * owned device pointers, hipStream_t as void*, 0 / negative status.  Argument blocks are plain C
+ * structs passed by pointer (host memory); the Python host mirrors them with ctypes.Structure
+ * (ctdd/unet_engine.py).  All activations are NHWC.
+ */
+#ifndef CTDD_UNET_H
+#define CTDD_UNET_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* K-segment kinds of the implicit-GEMM convolution */
+#define CTDD_SEG_3x3 0     /* 3x3, stride 1, pad 1                                   (unet.py:41-61)  */
+#define CTDD_SEG_1x1 1     /* 1x1: ResBlock linear skip / attention qkv, proj        (119-138,165-167)*/
+#define CTDD_SEG_3x3_S2 2  /* 3x3, stride 2, input padded (0,1,0,1)                  (88-97)          */
+#define CTDD_SEG_3x3_UP 3  /* 3x3 pad 1 on the nearest-2x upsampled input            (79-85)          */
+
+typedef struct { const void* hi; const float* f32; int C, kind; } ctdd_conv_seg;   /* [B][Hin][Win][C] bf16 | fp32 */
+typedef struct {
+  ctdd_conv_seg seg[3]; int nseg;
+  const void* w_hi; const float* w_f32;        /* [N][Ktot] bf16 | fp32, K = segment -> tap -> channel */
+  int B, H, W, Hin, Win, N, Ktot;
+  const float* bias; const float* tbias; int tb_stride;
+  const float* res_f32; const void* res_bf16;
+  float* out_f32; void* out_hi; double* stats; int logits_C;   /* stats: [B][N][2] fp64 sum / sum of squares */
+} ctdd_conv_args;
+/* out = conv(segments) + bias + tbias[b] + residual; bk in {96,64,32,16}, bnt = N-tile/32,
+ * f32 = 0: bf16 MFMA, 1: exact-fp32 MFMA */
+int ctdd_unet_conv(const void* conv_args, int bk, int bnt, int f32, void* stream);
+
+typedef struct {
+  const int64_t* x64; const int32_t* x32; float lo, hi; const float* w; const float* bias;
+  int B, Cin, H, W, Cout; float* out_f32; void* out_hi; double* stats; float* x0_f32;
+} ctdd_first_conv_args;
+/* center_data + first conv3x3 on the integer state (unet.py:428, network_utils.py:23-25) */
+int ctdd_unet_first_conv(const void* first_conv_args, void* stream);
+
+typedef struct {
+  const float* s1_f32; const void* s1_bf16; const double* st1; int C1;
+  const float* s2_f32; const void* s2_bf16; const double* st2; int C2;
+  const float* gamma; const float* beta; int B, HW, G; float eps; int swish; void* out_hi; float* out_f32;
+} ctdd_gn_args;
+/* GroupNorm (+Swish) of the channel concatenation of one or two tensors (unet.py:103-133, 403-416) */
+int ctdd_unet_gn_apply(const void* gn_args, void* stream);
+int ctdd_unet_channel_stats(const float* x, int B, int HW, int C, double* stats, void* stream);
+
+typedef struct {
+  const float* t; int B, ch, tdim; const float* w1; const float* b1; const float* w2; const float* b2; float* act;
+} ctdd_time_args;
+/* sinusoid -> Linear -> Swish -> Linear -> Swish, then every ResBlock's time projection (unet.py:223-241,332-337,110) */
+int ctdd_unet_time(const void* time_args, const float* proj_w, const float* proj_b, int Ntot, float* proj_out, void* stream);
+
+typedef struct { const float* qkv; int B, T, C, heads; void* out_hi; float* out_f32; } ctdd_attn_args;
+int ctdd_unet_attention(const void* attn_args, void* stream);              /* unet.py:176-200 */
+
+typedef struct { const float* net; const float* x0; int B, C, HW, S, fix; float* out; } ctdd_logistic_args;
+int ctdd_unet_logistic_head(const void* logistic_args, void* stream);      /* models.py:249-283 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

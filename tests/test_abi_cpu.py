@@ -17,7 +17,7 @@ def _built_lib():
 
 def test_header_symbols_exported():
     native = _built_lib()
-    hdr = open(os.path.join(ROOT, "include", "ctdd.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
     declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(ctdd_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 15
     lib = ctypes.CDLL(native.lib_path())
