@@ -59,9 +59,69 @@ struct ConvArgs {
   unsigned short* out_hi;     // [M][N] bf16 or null
   double* stats;              // [B][N][2] (sum, sumsq) in fp64 (no E[x^2]-mean^2 cancellation), atomics, or null
   int logits_C;               // > 0: out_f32 is (B, logits_C*H*W, N/logits_C): row = c*HW + p
+  int ksplit;                 // > 1: grid.z workgroups each take a share of K and add into acc_buf
+  float* acc_buf;             // [M][N] fp32, zeroed by the caller; finished by k_conv_finish
 };
 
 constexpr int BM = 128;
+
+// ------------------------------------------------------------------ epilogue shared by the conv kernels
+// One accumulator tile: lane column n, 16 registers = rows wrow0 + (r&3) + 8*(r>>2) + 4*g.
+__device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, int64_t wrow0, int n, int g,
+                                          int64_t M, int HW) {
+  const bool ncol = n < a.N;
+  if (a.ksplit > 1) {                                     // partial sums only; k_conv_finish does the rest
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t p = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (p < M && ncol) atomicAdd(a.acc_buf + (size_t)p * a.N + n, acc[r]);
+    }
+    return;
+  }
+  const int b_first = (int)((wrow0 < M ? wrow0 : M - 1) / HW);
+  const int64_t next_sample = (int64_t)(b_first + 1) * HW;   // a 32-row tile spans at most two samples (HW >= 32 or B small)
+  const float bv = (a.bias && ncol) ? a.bias[n] : 0.0f;
+  const float tb0 = (a.tbias && ncol) ? a.tbias[(size_t)b_first * a.tb_stride + n] : 0.0f;
+  const float tb1 = (a.tbias && ncol && b_first + 1 < a.B) ? a.tbias[(size_t)(b_first + 1) * a.tb_stride + n] : 0.0f;
+  const int S = a.logits_C > 0 ? a.N / a.logits_C : 1;
+  const int lch = a.logits_C > 0 ? n / S : 0, ls = a.logits_C > 0 ? n % S : 0;
+  double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;           // column sums for sample b_first / b_first+1
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t p = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+    if (p < M && ncol) {
+      const bool second = p >= next_sample;
+      float v = acc[r] + bv + (second ? tb1 : tb0);
+      const size_t o = (size_t)p * a.N + n;
+      if (a.res_f32) v += a.res_f32[o];
+      else if (a.res_bf16) v += from_bf16(a.res_bf16[o]);
+      if (a.out_f32) {
+        if (a.logits_C > 0) {
+          const int b = b_first + (second ? 1 : 0);
+          a.out_f32[(((size_t)b * a.logits_C + lch) * HW + (p - (int64_t)b * HW)) * S + ls] = v;
+        } else {
+          a.out_f32[o] = v;
+        }
+      }
+      if (a.out_hi) a.out_hi[o] = to_bf16(v);
+      if (second) { s1 += v; q1 += (double)v * v; } else { s0 += v; q0 += (double)v * v; }
+    }
+  }
+  if (a.stats) {
+    s0 += __shfl_xor(s0, 32, WAVE); q0 += __shfl_xor(q0, 32, WAVE);
+    s1 += __shfl_xor(s1, 32, WAVE); q1 += __shfl_xor(q1, 32, WAVE);
+    if (g == 0 && ncol) {
+      double* st = a.stats + ((size_t)b_first * a.N + n) * 2;
+      atomicAdd(st, s0);
+      atomicAdd(st + 1, q0);
+      if (b_first + 1 < a.B && (s1 != 0.0 || q1 != 0.0)) {
+        atomicAdd(st + (size_t)a.N * 2, s1);
+        atomicAdd(st + (size_t)a.N * 2 + 1, q1);
+      }
+    }
+  }
+}
+
 
 // K-chunk walker: (segment, tap, channel offset), all wave-uniform
 template <int BK>
@@ -224,49 +284,215 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
   }
 
   // ---- epilogue.  lane: column n = n0 + 32 t + li ; register r: row 32*wave + (r&3) + 8*(r>>2) + 4*g
-  const int64_t wrow0 = m0 + wave * 32;
-  const int b_first = (int)((wrow0 < M ? wrow0 : M - 1) / HW);
 #pragma unroll
-  for (int t = 0; t < BNT; ++t) {
-    const int n = n0 + 32 * t + li;
-    const bool ncol = n < a.N;
-    const float bv = (a.bias && ncol) ? a.bias[n] : 0.0f;
-    double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;         // column sums for sample b_first / b_first+1
+  for (int t = 0; t < BNT; ++t) conv_epilogue_tile(a, acc[t], m0 + wave * 32, n0 + 32 * t + li, g, M, HW);
+}
+
+// ------------------------------------------------------------------ patch convolution (bf16, stride 1)
+// The throughput kernel for 3x3 (pad 1) and 1x1 segments.  Output pixels are taken in flattened
+// (b, y, x) order, so the inputs of a tile of BM consecutive pixels under ALL nine taps live in one
+// contiguous slab of BM + 2(W+1) input pixels.  That slab (x BK channels) is staged in LDS ONCE
+// per channel chunk and the nine taps read it at row offsets (dy-1)*W + (dx-1); image borders and
+// sample boundaries are a per-lane predicate that zeroes the MFMA A fragment.  Compared with
+// im2col-per-tap staging this cuts the LDS store traffic (the ~79 B/clk/CU ds_write path) and
+// the L2 reads of the activations by ~6x; only the [BN][BK] weight tile is restaged per tap
+// (double-buffered, one barrier per tap).  The next slab is prefetched into registers under the
+// last taps.  4 waves, each WM rows x (32*BNT) columns; grid.z splits the channel chunks when M
+// is too small to fill the chip (7x7 levels), partial sums meet in acc_buf.
+template <int BK, int BNT, int WM>
+__global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
+  constexpr int BN = 32 * BNT, BMP = 4 * WM, MT = WM / 32;
+  constexpr int LDK = BK + 8, VPR = BK / 8;
+  constexpr int BV = (BN * VPR + 255) / 256;
+  constexpr int PVMAX = ((BMP + 2 * 34) * VPR + 255) / 256;     // W <= 33
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, g = lane >> 5;
+  const int HW = a.H * a.W, Wd = a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int64_t p0 = (int64_t)blockIdx.x * BMP;
+  const int n0 = blockIdx.y * BN;
+  const int halo = Wd + 1;
+  const int PR = BMP + 2 * halo;                                // slab rows
+  unsigned short* Ap = (unsigned short*)smem;                   // [PR][LDK]
+  unsigned short* Bs = Ap + (size_t)PR * LDK;                   // [2][BN][LDK]
+  const int npv = PR * VPR;                                     // slab vectors
+
+  // output pixel of this lane in every row tile: (y, x, in range)
+  int oy[MT], ox[MT];
+  bool oin[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t p = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (p < M && ncol) {
-        const int b = (int)(p / HW);
-        float v = acc[t][r] + bv;
-        if (a.tbias) v += a.tbias[(size_t)b * a.tb_stride + n];
-        const size_t o = (size_t)p * a.N + n;
-        if (a.res_f32) v += a.res_f32[o];
-        else if (a.res_bf16) v += from_bf16(a.res_bf16[o]);
-        if (a.out_f32) {
-          if (a.logits_C > 0) {
-            const int S = a.N / a.logits_C, ch = n / S, s = n % S;
-            a.out_f32[(((size_t)b * a.logits_C + ch) * HW + (p - (int64_t)b * HW)) * S + s] = v;
-          } else {
-            a.out_f32[o] = v;
-          }
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t p = p0 + wave * WM + mt * 32 + li;
+    oin[mt] = p < M;
+    const int r = (int)((oin[mt] ? p : 0) % HW);
+    oy[mt] = r / Wd; ox[mt] = r % Wd;
+  }
+
+  // ---- channel-chunk units (segment, c0) owned by this z-slice
+  int nunits = 0;
+  for (int sgi = 0; sgi < a.nseg; ++sgi) nunits += a.seg[sgi].C / BK;
+  const int zs = blockIdx.z, nz = a.ksplit > 1 ? a.ksplit : 1;
+
+  uint4 rp[PVMAX], rb[BV];
+  auto unit_info = [&](int u, int& sgi, int& c0, int& kbase) {   // kbase = K offset of (segment, tap 0, c0)
+    int k = 0;
+    sgi = 0;
+    while (u >= a.seg[sgi].C / BK) {
+      u -= a.seg[sgi].C / BK;
+      k += a.seg[sgi].C * (a.seg[sgi].kind == SEG_1x1 ? 1 : 9);
+      ++sgi;
+    }
+    c0 = u * BK;
+    kbase = k + c0;
+  };
+  auto load_patch = [&](int sgi, int c0) {
+    const ConvSeg sg = a.seg[sgi];
+    const int hl = sg.kind == SEG_1x1 ? 0 : halo;
+#pragma unroll
+    for (int i = 0; i < PVMAX; ++i) {
+      const int v = tid + 256 * i;
+      const int64_t q = p0 - hl + v / VPR;
+      const bool ok = v < npv && q >= 0 && q < M;
+      rp[i] = ok ? *(const uint4*)(sg.hi + (size_t)q * sg.C + c0 + (v % VPR) * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < PVMAX; ++i) {
+      const int v = tid + 256 * i;
+      if (v < npv) *(uint4*)(Ap + (size_t)(v / VPR) * LDK + (v % VPR) * 8) = rp[i];
+    }
+  };
+  auto load_b = [&](int koff) {
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int v = tid + 256 * i;
+      const int n = v / VPR;
+      const bool ok = v < BN * VPR && n0 + n < a.N;
+      rb[i] = ok ? *(const uint4*)(a.w_hi + (size_t)(n0 + n) * a.Ktot + koff + (v % VPR) * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int v = tid + 256 * i;
+      if (v < BN * VPR) *(uint4*)(Bs + ((size_t)buf * BN + v / VPR) * LDK + (v % VPR) * 8) = rb[i];
+    }
+  };
+
+  f32x16 acc[MT][BNT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.0f;
+
+  int u = zs;
+  int sgi, c0, kbase;
+  if (u < nunits) {
+    unit_info(u, sgi, c0, kbase);
+    load_patch(sgi, c0);
+    load_b(kbase);
+  }
+  int bbuf = 0;
+  while (u < nunits) {
+    const ConvSeg sg = a.seg[sgi];
+    const bool one = sg.kind == SEG_1x1;
+    const int ntap = one ? 1 : 9;
+    const int hl = one ? 0 : halo;
+    __syncthreads();                       // previous unit's slab and weight tiles are out of use
+    store_patch();
+    store_b(bbuf);
+    __syncthreads();
+    const int un = u + nz;                 // next unit of this slice
+    int nsgi = 0, nc0 = 0, nkbase = 0;
+    if (un < nunits) unit_info(un, nsgi, nc0, nkbase);
+    for (int tap = 0; tap < ntap; ++tap) {
+      // prefetch: next tap's weight tile, or (at the last tap) the next unit's first one + its slab
+      if (tap + 1 < ntap) load_b(kbase + (tap + 1) * sg.C);
+      else if (un < nunits) load_b(nkbase);
+      if (tap == (ntap > 4 ? 4 : 0) && un < nunits) load_patch(nsgi, nc0);
+      const int dy = one ? 1 : tap / 3, dx = one ? 1 : tap % 3;
+      const int shift = (dy - 1) * Wd + (dx - 1);
+      bool ok[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        ok[mt] = oin[mt] && (unsigned)(oy[mt] + dy - 1) < (unsigned)a.H && (unsigned)(ox[mt] + dx - 1) < (unsigned)Wd;
+      const unsigned short* Aw = Ap + (size_t)(hl + wave * WM + li + shift) * LDK + g * 8;
+      const unsigned short* Bw = Bs + ((size_t)bbuf * BN + li) * LDK + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          uint4 raw = *(const uint4*)(Aw + (size_t)mt * 32 * LDK + ks * 16);
+          if (!ok[mt]) raw = make_uint4(0, 0, 0, 0);
+          af[mt] = __builtin_bit_cast(bf16x8, raw);
         }
-        if (a.out_hi) a.out_hi[o] = to_bf16(v);
-        if (b == b_first) { s0 += v; q0 += (double)v * v; } else { s1 += v; q1 += (double)v * v; }
+#pragma unroll
+        for (int t = 0; t < BNT; ++t) {
+          const bf16x8 bf = *(const bf16x8*)(Bw + (size_t)t * 32 * LDK + ks * 16);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf, acc[mt][t], 0, 0, 0);
+        }
+      }
+      if (tap + 1 < ntap) {
+        store_b(bbuf ^ 1);                 // the other buffer was last read before the previous barrier
+        __syncthreads();
+        bbuf ^= 1;
       }
     }
-    if (a.stats) {
-      s0 += __shfl_xor(s0, 32, WAVE); q0 += __shfl_xor(q0, 32, WAVE);
-      s1 += __shfl_xor(s1, 32, WAVE); q1 += __shfl_xor(q1, 32, WAVE);
-      if (g == 0 && ncol) {
-        double* st = a.stats + ((size_t)b_first * a.N + n) * 2;
-        atomicAdd(st, s0);
-        atomicAdd(st + 1, q0);
-        if (b_first + 1 < a.B && (s1 != 0.0 || q1 != 0.0)) {
-          atomicAdd(st + (size_t)a.N * 2, s1);
-          atomicAdd(st + (size_t)a.N * 2 + 1, q1);
-        }
-      }
-    }
+    u = un; sgi = nsgi; c0 = nc0; kbase = nkbase;
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+      conv_epilogue_tile(a, acc[mt][t], p0 + wave * WM + mt * 32, n0 + 32 * t + li, g, M, HW);
+}
+
+// split-K finish: acc_buf (+ bias, time bias, residual) -> outputs and GroupNorm statistics
+__global__ __launch_bounds__(256) void k_conv_finish(const ConvArgs a) {
+  const int HW = a.H * a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int b = blockIdx.y;
+  // one workgroup per (sample, 32-column slab); threads stride over the sample's pixels
+  const int n = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (n >= a.N) return;
+  double s = 0.0, q = 0.0;
+  const float bv = a.bias ? a.bias[n] : 0.0f;
+  const float tb = a.tbias ? a.tbias[(size_t)b * a.tb_stride + n] : 0.0f;
+  for (int px = threadIdx.x >> 5; px < HW; px += 8) {
+    const int64_t p = (int64_t)b * HW + px;
+    const size_t o = (size_t)p * a.N + n;
+    float v = a.acc_buf[o] + bv + tb;
+    if (a.res_f32) v += a.res_f32[o];
+    else if (a.res_bf16) v += from_bf16(a.res_bf16[o]);
+    if (a.out_f32) a.out_f32[o] = v;
+    if (a.out_hi) a.out_hi[o] = to_bf16(v);
+    s += v; q += (double)v * v;
+  }
+  (void)M;
+  if (a.stats) {
+    atomicAdd(a.stats + ((size_t)b * a.N + n) * 2, s);
+    atomicAdd(a.stats + ((size_t)b * a.N + n) * 2 + 1, q);
+  }
+}
+
+// nearest-neighbour 2x upsampling of an NHWC bf16 tensor (input of the Upsample conv, unet.py:79-85)
+__global__ __launch_bounds__(256) void k_upsample2x(const unsigned short* __restrict__ x, int B, int H, int W, int C,
+                                                    unsigned short* __restrict__ out) {
+  const int vpp = C / 8;
+  const int64_t total = (int64_t)B * 4 * H * W * vpp;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(v % vpp);
+    const int64_t p = v / vpp;
+    const int xo = (int)(p % (2 * W)), yo = (int)((p / (2 * W)) % (2 * H)), b = (int)(p / ((int64_t)4 * H * W));
+    *(uint4*)(out + (size_t)p * C + cv * 8) = *(const uint4*)(x + (((size_t)b * H + (yo >> 1)) * W + (xo >> 1)) * C + cv * 8);
   }
 }
 
@@ -284,44 +510,49 @@ struct FirstConvArgs {
   float* x0_f32;              // optional centred input (B,Cin,H,W) fp32 (logistic head needs it)
 };
 __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
-  const int cg = a.Cout / 8;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)a.B * a.H * a.W * cg;
-  if (idx >= total) return;
-  const int c8 = (int)(idx % cg);
-  const int64_t p = idx / cg;
-  const int HW = a.H * a.W;
-  const int b = (int)(p / HW), r = (int)(p % HW), y = r / a.W, x = r % a.W;
-  float acc[8];
+  extern __shared__ __attribute__((aligned(16))) double sred[];     // [Cout][2] per-workgroup partial statistics
+  const int cg = a.Cout / 8, HW = a.H * a.W, b = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) sred[i] = 0.0;
+  __syncthreads();
+  const int per = (HW * cg + gridDim.x - 1) / gridDim.x;             // (pixel, channel-group) items per workgroup
+  const int lo = blockIdx.x * per, hi_ = min(lo + per, HW * cg);
+  for (int item = lo + threadIdx.x; item < hi_; item += 256) {
+    const int c8 = item % cg, r = item / cg, y = r / a.W, x = r % a.W;
+    float acc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = a.bias[c8 * 8 + j];
-  for (int ci = 0; ci < a.Cin; ++ci)
-    for (int dy = 0; dy < 3; ++dy)
-      for (int dx = 0; dx < 3; ++dx) {
-        const int yy = y + dy - 1, xx = x + dx - 1;
-        if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
-        const size_t o = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
+    for (int j = 0; j < 8; ++j) acc[j] = a.bias[c8 * 8 + j];
+    for (int ci = 0; ci < a.Cin; ++ci)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+          const int yy = y + dy - 1, xx = x + dx - 1;
+          if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+          const size_t o = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
+          const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
+          const float v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, a.w[(((size_t)(c8 * 8 + j) * a.Cin + ci) * 3 + dy) * 3 + dx], acc[j]);
+        }
+    if (a.x0_f32 && c8 == 0)
+      for (int ci = 0; ci < a.Cin; ++ci) {
+        const size_t o = (((size_t)b * a.Cin + ci) * a.H + y) * a.W + x;
         const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
-        const float v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, a.w[(((size_t)(c8 * 8 + j) * a.Cin + ci) * 3 + dy) * 3 + dx], acc[j]);
+        a.x0_f32[o] = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
       }
-  if (a.x0_f32 && c8 == 0)
-    for (int ci = 0; ci < a.Cin; ++ci) {
-      const size_t o = (((size_t)b * a.Cin + ci) * a.H + y) * a.W + x;
-      const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
-      a.x0_f32[o] = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
-    }
-  const size_t o = (size_t)p * a.Cout + c8 * 8;
+    const size_t o = ((size_t)b * HW + r) * a.Cout + c8 * 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = acc[j];
-    if (a.out_f32) a.out_f32[o + j] = v;
-    if (a.out_hi) a.out_hi[o + j] = to_bf16(v);
-    if (a.stats) {
-      atomicAdd(a.stats + ((size_t)b * a.Cout + c8 * 8 + j) * 2, (double)v);
-      atomicAdd(a.stats + ((size_t)b * a.Cout + c8 * 8 + j) * 2 + 1, (double)v * v);
+    for (int j = 0; j < 8; ++j) {
+      const float v = acc[j];
+      if (a.out_f32) a.out_f32[o + j] = v;
+      if (a.out_hi) a.out_hi[o + j] = to_bf16(v);
+      if (a.stats) {
+        atomicAdd(&sred[(c8 * 8 + j) * 2], (double)v);
+        atomicAdd(&sred[(c8 * 8 + j) * 2 + 1], (double)v * v);
+      }
     }
+  }
+  if (a.stats) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) atomicAdd(a.stats + (size_t)b * a.Cout * 2 + i, sred[i]);
   }
 }
 
@@ -562,11 +793,63 @@ extern "C" int ctdd_unet_conv(const void* args_, int bk, int bnt, int f32, void*
   CTDD_REQUIRE(false, CTDD_ERANGE, "no conv instantiation for BK=%d BNT=%d", bk, bnt);
 }
 
+template <int BK, int BNT, int WM>
+static int launch_patch(const ConvArgs& a, hipStream_t st) {
+  constexpr int LDK = BK + 8;
+  const int PR = 4 * WM + 2 * (a.W + 1);
+  const size_t lds = ((size_t)PR + 2 * 32 * BNT) * LDK * 2;
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  dim3 g((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), a.ksplit > 1 ? a.ksplit : 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_conv_patch<BK, BNT, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM>), g, dim3(256), lds, st, a);
+  if (int rc = finish_launch("k_conv_patch")) return rc;
+  if (a.ksplit > 1) {
+    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
+    return finish_launch("k_conv_finish");
+  }
+  return CTDD_OK;
+}
+
+extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, void* stream) {
+  const ConvArgs& a = *(const ConvArgs*)args_;
+  CTDD_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.w_hi, CTDD_EINVAL, "bad conv arguments");
+  CTDD_REQUIRE(a.W <= 33, CTDD_ERANGE, "W=%d > 33", a.W);
+  CTDD_REQUIRE(a.Hin == a.H && a.Win == a.W, CTDD_EINVAL, "patch conv is stride 1");
+  for (int i = 0; i < a.nseg; ++i) {
+    CTDD_REQUIRE(a.seg[i].hi && a.seg[i].C % bk == 0, CTDD_EINVAL, "segment %d: C=%d vs BK=%d", i, a.seg[i].C, bk);
+    CTDD_REQUIRE(a.seg[i].kind == SEG_3x3 || a.seg[i].kind == SEG_1x1, CTDD_EINVAL, "segment %d: kind %d", i, a.seg[i].kind);
+  }
+  CTDD_REQUIRE(a.ksplit <= 1 || (a.acc_buf && a.logits_C == 0), CTDD_EINVAL, "split-K needs acc_buf");
+  hipStream_t st = (hipStream_t)stream;
+#define CASEP(BK_, BNT_, WM_) if (bk == BK_ && bnt == BNT_ && wm == WM_) return launch_patch<BK_, BNT_, WM_>(a, st);
+  CASEP(48, 3, 64) CASEP(48, 3, 32) CASEP(48, 4, 64) CASEP(48, 4, 32)
+  CASEP(64, 4, 64) CASEP(64, 4, 32) CASEP(64, 2, 64) CASEP(64, 2, 32) CASEP(32, 1, 32) CASEP(32, 3, 32) CASEP(32, 4, 32)
+  CASEP(16, 1, 32)
+#undef CASEP
+  CTDD_REQUIRE(false, CTDD_ERANGE, "no patch-conv instantiation for BK=%d BNT=%d WM=%d", bk, bnt, wm);
+}
+
+extern "C" int ctdd_unet_upsample2x(const void* x, int B, int H, int W, int C, void* out, void* stream) {
+  CTDD_REQUIRE(x && out && C % 8 == 0, CTDD_EINVAL, "bad upsample arguments");
+  const int64_t total = (int64_t)B * 4 * H * W * (C / 8);
+  int gx = (int)((total + 255) / 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(k_upsample2x, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, B, H, W, C,
+                     (unsigned short*)out);
+  return finish_launch("k_upsample2x");
+}
+
 extern "C" int ctdd_unet_first_conv(const void* args_, void* stream) {
   const FirstConvArgs& a = *(const FirstConvArgs*)args_;
   CTDD_REQUIRE((a.x64 || a.x32) && a.w && a.bias && a.Cout % 8 == 0, CTDD_EINVAL, "bad first-conv arguments");
-  const int64_t total = (int64_t)a.B * a.H * a.W * (a.Cout / 8);
-  hipLaunchKernelGGL(k_first_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const int items = a.H * a.W * (a.Cout / 8);
+  int gx = (items + 1023) / 1024;            // ~4 items per thread: few global atomics, enough workgroups
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_first_conv, dim3(gx, a.B), dim3(256), (size_t)2 * a.Cout * sizeof(double), (hipStream_t)stream, a);
   return finish_launch("k_first_conv");
 }
 

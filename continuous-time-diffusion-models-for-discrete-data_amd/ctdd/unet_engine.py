@@ -31,7 +31,8 @@ class _Seg(C.Structure):
 class _ConvArgs(C.Structure):
     _fields_ = [("seg", _Seg * 3), ("nseg", _I), ("w_hi", _P), ("w_f32", _P), ("B", _I), ("H", _I), ("W", _I),
                 ("Hin", _I), ("Win", _I), ("N", _I), ("Ktot", _I), ("bias", _P), ("tbias", _P), ("tb_stride", _I),
-                ("res_f32", _P), ("res_bf16", _P), ("out_f32", _P), ("out_hi", _P), ("stats", _P), ("logits_C", _I)]
+                ("res_f32", _P), ("res_bf16", _P), ("out_f32", _P), ("out_hi", _P), ("stats", _P), ("logits_C", _I),
+                ("ksplit", _I), ("acc_buf", _P)]
 
 
 class _FirstArgs(C.Structure):
@@ -65,7 +66,8 @@ def _lib():
     global _sigs_done
     lib = native.load()
     if not _sigs_done:
-        for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_first_conv", [_P, _P]),
+        for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_patch", [_P, _I, _I, _I, _P]),
+                           ("ctdd_unet_upsample2x", [_P, _I, _I, _I, _I, _P, _P]), ("ctdd_unet_first_conv", [_P, _P]),
                            ("ctdd_unet_gn_apply", [_P, _P]), ("ctdd_unet_channel_stats", [_P, _I, _I, _I, _P, _P]),
                            ("ctdd_unet_time", [_P, _P, _P, _I, _P, _P]), ("ctdd_unet_attention", [_P, _P]),
                            ("ctdd_unet_logistic_head", [_P, _P])):
@@ -180,6 +182,7 @@ class UNetEngine:
             return 1
 
         stats_views = []          # (tensor, offset) resolved after the pool exists
+        zero_views = []           # split-K partial-sum buffers: (conv args, elements)
 
         def conv(segs, w2d, bias, N, Hout, Wout, Hin, Win, out, tb=None, res=None, logits_C=0, out_f32_tensor=None):
             """segs: list of (_Tensor, channels, kind)."""
@@ -206,10 +209,32 @@ class UNetEngine:
                 if out.stats is not None:
                     stats_views.append((a, out.stats))
             a.logits_C = logits_C
-            bk = pick_bk([s[1] for s in segs])
-            bnt = pick_bnt(N, bk)
             keep.append(a)
-            launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise))
+            cs = [s[1] for s in segs]
+            patchable = (not self.precise) and all(s[2] in (SEG_3x3, SEG_1x1) for s in segs) and Wout <= 33
+            if patchable:
+                # throughput kernel: slab staged once per channel chunk (csrc/unet_kernels.hip: k_conv_patch)
+                if all(c % 48 == 0 for c in cs) and (N % 96 == 0 or N % 128 == 0):
+                    bk, bnt = 48, (3 if N % 96 == 0 else 4)
+                elif all(c % 64 == 0 for c in cs) and N % 64 == 0:
+                    bk, bnt = 64, (4 if N % 128 == 0 else 2)
+                elif all(c % 32 == 0 for c in cs):
+                    bk, bnt = 32, (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
+                else:
+                    bk, bnt = 16, 1
+                M_ = B * Hout * Wout
+                wm = 64 if (bnt <= 3 and bk in (48, 64) and M_ >= 256 * 256) else 32
+                ntiles = -(-M_ // (4 * wm)) * -(-N // (32 * bnt))
+                units = sum(c // bk for c in cs)
+                if ntiles < 384 and units >= 2 and logits_C == 0 and out_f32_tensor is None:
+                    a.ksplit = max(1, min(units, -(-640 // ntiles)))
+                if a.ksplit > 1:
+                    zero_views.append((a, M_ * N))
+                launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm)
+            else:
+                bk = pick_bk(cs)
+                bnt = pick_bnt(N, bk)
+                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise))
 
         def gn_apply(srcs, norm, swish, eps, HW):
             """srcs: one or two _Tensor; returns activated planes tensor."""
@@ -344,8 +369,14 @@ class UNetEngine:
             else:                                      # Upsample: nearest x2 folded into the conv's addressing
                 cv = layer[1]
                 y = _Tensor(self, B, cur.H * 2, cur.W * 2, cur.C)
-                conv([(cur, cur.C, SEG_3x3_UP)], self._conv_w(cv.weight.detach().float(), [cur.C]),
-                     cv.bias.detach().float().contiguous(), cur.C, cur.H * 2, cur.W * 2, cur.H, cur.W, y)
+                if self.precise:
+                    conv([(cur, cur.C, SEG_3x3_UP)], self._conv_w(cv.weight.detach().float(), [cur.C]),
+                         cv.bias.detach().float().contiguous(), cur.C, cur.H * 2, cur.W * 2, cur.H, cur.W, y)
+                else:                                  # bf16: materialise the 2x grid (cheap), then the patch kernel
+                    up = _Tensor(self, B, cur.H * 2, cur.W * 2, cur.C, stats=False)
+                    launch(lib.ctdd_unet_upsample2x, ptr(cur.hi), B, cur.H, cur.W, cur.C, ptr(up.hi))
+                    conv([(up, cur.C, SEG_3x3)], self._conv_w(cv.weight.detach().float(), [cur.C]),
+                         cv.bias.detach().float().contiguous(), cur.C, up.H, up.W, up.H, up.W, y)
                 cur = y
         ao = gn_apply([cur], net.out[0], True, net.out[0].eps, cur.H * cur.W)
         oc = net.out[2]
@@ -375,12 +406,19 @@ class UNetEngine:
                 item[0].stats = base + 8 * item[1]
             else:
                 setattr(item[0], item[2], base + 8 * item[1])
+        nz = sum(n for _, n in zero_views)
+        st.zpool = torch.zeros((max(nz, 1),), dtype=torch.float32, device=dev)
+        zo = 0
+        for a_, n in zero_views:
+            a_.acc_buf = st.zpool.data_ptr() + 4 * zo
+            zo += n
         st.plan, st.keep, st.graph = plan, keep, None
         return st
 
     # ------------------------------------------------------------------ execution
     def _run_plan(self, st):
         st.stats.zero_()
+        st.zpool.zero_()
         for step in st.plan:
             step()
 

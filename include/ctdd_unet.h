@@ -29,10 +29,15 @@ typedef struct {
   const float* bias; const float* tbias; int tb_stride;
   const float* res_f32; const void* res_bf16;
   float* out_f32; void* out_hi; double* stats; int logits_C;   /* stats: [B][N][2] fp64 sum / sum of squares */
+  int ksplit; float* acc_buf;                                  /* split-K: zeroed [M][N] fp32 partial-sum buffer */
 } ctdd_conv_args;
 /* out = conv(segments) + bias + tbias[b] + residual; bk in {96,64,32,16}, bnt = N-tile/32,
  * f32 = 0: bf16 MFMA, 1: exact-fp32 MFMA */
 int ctdd_unet_conv(const void* conv_args, int bk, int bnt, int f32, void* stream);
+/* bf16 throughput kernel for stride-1 3x3 / 1x1 segments: the input slab of a pixel tile is staged in
+ * LDS once per channel chunk and shared by the nine taps; bk in {48,64,32,16}, wm = rows per wave */
+int ctdd_unet_conv_patch(const void* conv_args, int bk, int bnt, int wm, void* stream);
+int ctdd_unet_upsample2x(const void* x_bf16, int B, int H, int W, int C, void* out_bf16, void* stream);   /* unet.py:79-85 */
 
 typedef struct {
   const int64_t* x64; const int32_t* x32; float lo, hi; const float* w; const float* bias;
