@@ -170,7 +170,7 @@ def main():
             "metric": "tau-leaping sample-steps/s", "value": round(value, 2), "unit": "sample-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
+            "dtype": "bf16 score network (fp32 accumulate) + f32 rates/softmax with split-bf16 MFMA contraction", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
             "config": {"workload": "MNIST tauLDR U-Net TauL step (config_tauUnet_mnist: D=784, S=256, 1000-step grid)",
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "D": D, "S": S,
                        "parallelism": f"sample-sharded x{world}, no collective in the loop"},
