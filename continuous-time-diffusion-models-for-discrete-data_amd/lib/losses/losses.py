@@ -1,0 +1,276 @@
+"""Training losses behind the reference's registry names (lib/losses/losses.py): CTElbo 12-287,
+NLL 1504-1778, CTElboLambda 1783-2058, CatRM 786-890, CatRMNLL 1135-1242, NLLOriginal 1049-1103,
+ScoreElbo 1246-1500.
+
+Every loss = forward noising x0 -> x_t (and, for the ELBO family, the one-jump neighbour x~) followed
+by an objective on the network's logits.  Noising runs in the HIP kernels K1/K2/K3 (per-sample
+q_{t|0} / R_t tables, exponential-race categorical draws, csrc/noising.hip) with a Philox key taken
+from torch's generator; the objectives are written as batched gathers and (B,D,S)x(B,S,S) products on
+the device so autograd reaches the network (no index-vector construction, SURVEY 6: 63 % of the
+reference's CPU time there).  Both argument orders of the reference are accepted: the class-level
+`calc_loss(state, minibatch, label=None)` and the stale `calc_loss(minibatch, state)`.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import lib.losses.losses_utils as losses_utils
+import lib.utils.utils as utils
+from ctdd import native
+from lib.models.model_utils import get_logprob_with_logits
+
+
+def _seed():
+    return int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+
+
+def _unpack(a, b):
+    """(state, minibatch) in either order."""
+    return (a, b) if isinstance(a, dict) else (b, a)
+
+
+def _flatten(minibatch):
+    if minibatch.dim() == 4:
+        B, C, H, W = minibatch.shape
+        minibatch = minibatch.view(B, C * H * W)
+    return minibatch
+
+
+# Parity-test hook: {"ts": (B,), "x_t": (B,D), "x_tilde": (B,D)} replaces the random draws so that the
+# objective can be compared with the oracle on identical noise (tests/test_gpu_losses.py).
+_FIXED_NOISE = None
+
+
+def _draw_ts(B, device, lo, hi):
+    if _FIXED_NOISE is not None:
+        return _FIXED_NOISE["ts"].to(device)
+    return torch.rand((B,), device=device) * (hi - lo) + lo
+
+
+def _noise(model, x0, ts, with_tilde):
+    """x_t ~ q_{t|0}(.|x0) per dimension and optionally the one-jump neighbour x~ (losses.py:39-101).
+    Returns qt0, rate (B,S,S) and int64 x_t[, x~]."""
+    if _FIXED_NOISE is not None:
+        qt0, _, rate, _ = model.process.tables(ts, want_qt0=True, want_rate=True)
+        xt = _FIXED_NOISE["x_t"].to(x0.device).long()
+        return qt0, rate, xt, (_FIXED_NOISE["x_tilde"].to(x0.device).long() if with_tilde else None)
+    qt0, _, rate, probs = model.process.tables(ts, want_qt0=True, want_rate=True, want_noise_probs=True)
+    x0i = x0.to(torch.int32).contiguous()
+    x_t = native.noise_categorical(probs, x0i, seed=_seed())
+    if not with_tilde:
+        return qt0, rate, x_t.long(), None
+    _, _, x_tilde = native.xtilde_sample(rate, x_t, seed=_seed())
+    return qt0, rate, x_t.long(), x_tilde.long()
+
+
+def _masked_rows(tab, x):
+    """tab (B,S,S), x (B,D) -> tab[b, x_bd, :] with entry x_bd zeroed: (B,D,S)."""
+    rows = tab[torch.arange(tab.shape[0], device=tab.device).view(-1, 1), x]
+    return rows.scatter(-1, x.unsqueeze(-1), 0.0)
+
+
+def _ct_elbo_terms(logits_reg, logits_sig, x0, reg_x, x_tilde, qt0, rate, eps):
+    """Negative CT-ELBO of tauLDR (losses.py:106-278): mean(-sig/norm) + mean(reg)."""
+    B = x0.shape[0]
+    n = torch.arange(B, device=x0.device).view(B, 1)
+    qT, rT = qt0.transpose(1, 2), rate.transpose(1, 2)            # qT[b,x,s0] = qt0[b,s0,x]; rT[b,x,s] = rate[b,s,x]
+    p_reg = F.softmax(logits_reg, dim=2)
+    reg_tmp = _masked_rows(rT, reg_x) @ qT                        # sum_s (mask*rate[s,x]) qt0[s0,s]
+    reg_term = torch.sum((p_reg / (qT[n, reg_x] + eps)) * reg_tmp, dim=(1, 2))
+    p_sig = p_reg if logits_sig is logits_reg else F.softmax(logits_sig, dim=2)
+    inner = torch.log((p_sig / (qT[n, x_tilde] + eps)) @ qt0 + eps)
+    outer_rate = _masked_rows(rT, x_tilde)                        # rate[b, s, x~], s != x~
+    q_x0 = qt0[n, x0]                                             # qt0[b, x0, s]
+    q_x0_xt = torch.gather(q_x0, -1, x_tilde.unsqueeze(-1)) + eps  # (B,D,1)
+    outer = torch.sum(outer_rate * (q_x0 / q_x0_xt) * inner, dim=(1, 2))
+    row_sums = -torch.diagonal(rate, dim1=1, dim2=2)              # (B,S)
+    base_tmp = row_sums[n, x_tilde]                               # (B,D)
+    Z = base_tmp.sum(1).view(B, 1, 1) - base_tmp.unsqueeze(-1) + row_sums.unsqueeze(1)
+    sig_norm = torch.sum(outer_rate * q_x0 / (Z * q_x0_xt), dim=(1, 2))
+    return torch.mean(-outer / sig_norm) + torch.mean(reg_term)
+
+
+class _CTElboBase:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ratio_eps = cfg.loss.eps_ratio
+        self.nll_weight = cfg.loss.nll_weight
+        self.min_time = cfg.loss.min_time
+        self.one_forward_pass = cfg.loss.one_forward_pass
+        self.max_t = cfg.training.max_t
+        self.cross_ent = nn.CrossEntropyLoss()
+
+    def _pieces(self, state, minibatch):
+        model = state["model"]
+        x0 = _flatten(minibatch).long()
+        B = x0.shape[0]
+        ts = _draw_ts(B, model.device, self.min_time, self.max_t)
+        qt0, rate, x_t, x_tilde = _noise(model, x0, ts, True)
+        x_logits = model(x_t, ts)
+        if self.one_forward_pass:
+            logits_sig, reg_x = x_logits, x_tilde
+        else:
+            logits_sig, reg_x = model(x_tilde, ts), x_t
+        neg_elbo = _ct_elbo_terms(x_logits, logits_sig, x0, reg_x, x_tilde, qt0, rate, self.ratio_eps)
+        nll = self.cross_ent(x_logits.permute(0, 2, 1), x0)
+        return neg_elbo, nll
+
+
+@losses_utils.register_loss
+class CTElbo(_CTElboBase):
+    def calc_loss(self, state, minibatch, label=None):
+        state, minibatch = _unpack(state, minibatch)
+        neg_elbo, nll = self._pieces(state, minibatch)
+        return neg_elbo + self.nll_weight * nll
+
+
+@losses_utils.register_loss
+class NLL(_CTElboBase):
+    """Same sampling path as CTElbo, returns only the cross entropy (losses.py:1504-1778)."""
+
+    def calc_loss(self, state, minibatch, label=None):
+        state, minibatch = _unpack(state, minibatch)
+        return self._pieces(state, minibatch)[1]
+
+
+@losses_utils.register_loss
+class CTElboLambda(_CTElboBase):
+    """w * neg_elbo + (1 - w) * nll with w = n_iter / n_iters (losses.py:1783-2058)."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.max_iter = cfg.training.n_iters
+
+    def calc_loss(self, state, minibatch, label=None):
+        state, minibatch = _unpack(state, minibatch)
+        w = state["n_iter"] / self.max_iter
+        neg_elbo, nll = self._pieces(state, minibatch)
+        return w * neg_elbo + (1 - w) * nll
+
+
+def _crm_loss(cfg, model, xt, t, ll_all, ll_xt):
+    """Categorical ratio matching objectives (losses.py:794-836): rm / mle / elbo, per (b,d)."""
+    S = cfg.data.S
+    lt = cfg.loss.loss_type
+    if lt == "rm":
+        return -ll_xt
+    if lt == "mle":
+        return -((S - 1) * ll_xt + torch.sum(utils.log1mexp(ll_all), dim=-1) - utils.log1mexp(ll_xt))
+    if lt == "elbo":
+        qt0 = model.transition(t)
+        n = torch.arange(xt.shape[0], device=xt.device).view(-1, 1)
+        d = ll_all - ll_xt.unsqueeze(-1)
+        own = F.one_hot(xt, S).to(ll_all.dtype)
+        first = torch.sum(torch.exp(d) * qt0.transpose(1, 2)[n, xt] * (1 - own), dim=-1)
+        second = torch.sum(-d * qt0[n, xt] * (1 - own), dim=-1)
+        return first - second
+    raise ValueError("Unknown loss_type: %s" % lt)
+
+
+class _CRMBase:
+    clamp_t = True
+    t_hi = 1.0
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ratio_eps = cfg.loss.eps_ratio
+        self.min_time = cfg.loss.min_time
+        self.S = cfg.data.S
+        self.D = cfg.model.concat_dim
+
+    def _forward(self, state, minibatch):
+        model = state["model"]
+        x0 = _flatten(minibatch).long()
+        B = x0.shape[0]
+        ts = _draw_ts(B, model.device, self.min_time, self.t_hi)
+        if self.clamp_t:
+            ts = torch.clamp(ts, max=0.99999)
+        _, _, xt, _ = _noise(model, x0, ts, False)
+        return model, x0, ts, xt
+
+
+@losses_utils.register_loss
+class CatRM(_CRMBase):
+    def calc_loss(self, state, minibatch, label=None):
+        state, minibatch = _unpack(state, minibatch)
+        model, x0, ts, xt = self._forward(state, minibatch)
+        logits = model(xt, ts)
+        ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, xt, ts, logits)
+        loss = _crm_loss(self.cfg, model, xt, ts, ll_all, ll_xt) * (1 - self.cfg.loss.ce_coeff)
+        return torch.sum(loss) / x0.shape[0]
+
+
+@losses_utils.register_loss
+class CatRMNLL(_CRMBase):
+    """CatRM + nll_weight * CE(logits, x0), t ~ U(min_time, max_t) without clamp (losses.py:1135-1242)."""
+    clamp_t = False
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.t_hi = cfg.training.max_t
+        self.nll_weight = cfg.loss.nll_weight
+        self.cross_ent = nn.CrossEntropyLoss()
+
+    def calc_loss(self, minibatch, state=None, label=None):
+        state, minibatch = _unpack(minibatch, state)
+        model, x0, ts, xt = self._forward(state, minibatch)
+        logits = model(xt, ts)
+        ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, xt, ts, logits)
+        loss = _crm_loss(self.cfg, model, xt, ts, ll_all, ll_xt) * (1 - self.cfg.loss.ce_coeff)
+        nll = self.cross_ent(logits.permute(0, 2, 1), x0)
+        return torch.sum(loss) / x0.shape[0] + self.nll_weight * nll
+
+
+@losses_utils.register_loss
+class NLLOriginal(_CRMBase):
+    """Plain denoising cross entropy, t ~ U(min_time, 1) unclamped (losses.py:1049-1103)."""
+    clamp_t = False
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.cross_ent = nn.CrossEntropyLoss()
+
+    def calc_loss(self, state, minibatch, label=None):
+        state, minibatch = _unpack(state, minibatch)
+        model, x0, ts, xt = self._forward(state, minibatch)
+        logits = model(xt, ts) if label is None else model(xt, ts, label)
+        return self.cross_ent(logits.permute(0, 2, 1), x0)
+
+
+@losses_utils.register_loss
+class ScoreElbo:
+    """CT-ELBO evaluated with SDDM ratios exp(ll_all - ll_xt) + nll_weight * mean(-ll_xt)
+    (losses.py:1246-1500)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ratio_eps = cfg.loss.eps_ratio
+        self.nll_weight = cfg.loss.nll_weight
+        self.min_time = cfg.loss.min_time
+        self.one_forward_pass = cfg.loss.one_forward_pass
+
+    def calc_loss(self, minibatch, state=None, label=None):
+        state, minibatch = _unpack(minibatch, state)
+        model = state["model"]
+        x0 = _flatten(minibatch).long()
+        B = x0.shape[0]
+        eps = self.ratio_eps
+        ts = torch.clamp(_draw_ts(B, model.device, self.min_time, 1.0), max=0.99999)
+        qt0, rate, x_t, x_tilde = _noise(model, x0, ts, True)
+        reg_x = x_tilde if self.one_forward_pass else x_t
+        logits = model(reg_x, ts)
+        n = torch.arange(B, device=x0.device).view(B, 1)
+        rT = rate.transpose(1, 2)
+        ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, x_tilde, ts, logits)
+        d = ll_all - ll_xt.unsqueeze(-1)
+        reg_term = torch.sum(torch.exp(d) * _masked_rows(rT, reg_x), dim=(1, 2))
+        outer_rate = _masked_rows(rT, x_tilde)
+        q_x0 = qt0[n, x0]
+        q_x0_xt = torch.gather(q_x0, -1, x_tilde.unsqueeze(-1)) + eps
+        outer = torch.sum(outer_rate * (q_x0 / q_x0_xt) * d, dim=(1, 2))
+        row_sums = -torch.diagonal(rate, dim1=1, dim2=2)
+        base_tmp = row_sums[n, x_tilde]
+        Z = base_tmp.sum(1).view(B, 1, 1) - base_tmp.unsqueeze(-1) + row_sums.unsqueeze(1)
+        sig_norm = torch.sum(outer_rate * q_x0 / (Z * q_x0_xt), dim=(1, 2))
+        neg_elbo = torch.mean(-outer / sig_norm) + torch.mean(reg_term)
+        return neg_elbo + self.nll_weight * (torch.sum(-ll_xt) / B)

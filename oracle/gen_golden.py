@@ -279,8 +279,75 @@ def gen_unet():
     save("unet", **arrs)
 
 
+# ------------------------------------------------------------------------------------ P7 (losses)
+def gen_losses():
+    """Reference losses on the toy score function under a fixed seed.  The noised states the
+    reference drew are captured from the model calls; E noise is regenerated in its RNG order so
+    that the oracle can rebuild x_t / x~ itself.  d(loss)/d(scale) pins the gradient path."""
+    arrs = {}
+    cases = [
+        # tag, loss, kind, S, B, D, overrides
+        ("ctelbo_g16", "CTElbo", "gaussian", 16, 4, 12, dict(nll_weight=0.3)),
+        ("ctelbo2_g16", "CTElbo", "gaussian", 16, 4, 12, dict(one_forward_pass=False, nll_weight=0.0)),
+        ("nll_g16", "NLL", "gaussian", 16, 4, 12, dict()),
+        ("lambda_g16", "CTElboLambda", "gaussian", 16, 4, 12, dict(n_iter=250)),
+        ("ctelbo_g256", "CTElbo", "gaussian", 256, 2, 9, dict(nll_weight=0.001)),
+        ("catrm_v3_rm", "CatRM", "univar", 3, 5, 15, dict(logit_type="reverse_prob", loss_type="rm")),
+        ("catrm_v3_mle", "CatRM", "univar", 3, 5, 15, dict(logit_type="direct", loss_type="mle")),
+        ("catrm_v3_elbo", "CatRM", "univar", 3, 5, 15, dict(logit_type="reverse_logscale", loss_type="elbo", ce_coeff=0.25)),
+        ("catrmnll_v2", "CatRMNLL", "univar", 2, 6, 32, dict(logit_type="reverse_prob", loss_type="rm", nll_weight=0.01, t_func="log_sqr", max_t=0.99999)),
+        ("catrmnll_g16_elbo", "CatRMNLL", "gaussian", 16, 3, 10, dict(logit_type="direct", loss_type="elbo", nll_weight=0.1)),
+        ("nllorig_v3", "NLLOriginal", "univar", 3, 5, 15, dict()),
+        ("score_v3", "ScoreElbo", "univar", 3, 5, 15, dict(logit_type="reverse_prob", nll_weight=0.01)),
+        ("score_g16", "ScoreElbo", "gaussian", 16, 4, 12, dict(logit_type="direct", nll_weight=0.5, one_forward_pass=False)),
+    ]
+    for tag, lname, kind, S, B, D, ov in cases:
+        cfg = base_cfg(S, D)
+        cfg.loss.name = lname
+        for k in ("nll_weight", "one_forward_pass", "logit_type", "loss_type", "ce_coeff"):
+            if k in ov:
+                cfg.loss[k] = ov[k]
+        cfg.model.t_func = ov.get("t_func", "sqrt_cos")
+        cfg.training.max_t = ov.get("max_t", 1.0)
+        model = make_ref_model(kind, cfg)
+        theta = torch.tensor(1.5, requires_grad=True)
+        model.calls = []
+        base_call = model.__class__.__call__
+
+        def call(self, x, t, *a, _th=theta, _S=S):
+            self.calls.append((x.clone(), t.clone()))
+            return toy_logits(x, t, _S, 1.0) * _th
+        model.__class__.__call__ = call
+        loss = getattr(ref_losses, lname)(cfg)
+        g = torch.Generator().manual_seed(17)
+        x0 = torch.randint(0, S, (B, D), generator=g)
+        state = {"model": model, "n_iter": ov.get("n_iter", 0)}
+        seed = 777
+        torch.manual_seed(seed)
+        old_order = lname in ("CatRMNLL", "ScoreElbo")
+        val = loss.calc_loss(x0.clone(), state) if old_order else loss.calc_loss(state, x0.clone())
+        grad, = torch.autograd.grad(val, theta)
+        ts = model.calls[0][1]
+        # regenerate the noise in the reference's RNG order
+        torch.manual_seed(seed)
+        u = torch.rand((B,))
+        E_xt = torch.empty(B * D, S).exponential_(1)
+        extra = {}
+        if lname in ("CTElbo", "NLL", "CTElboLambda", "ScoreElbo"):
+            extra = {"E_dim": torch.empty(B, D).exponential_(1), "E_val": torch.empty(B, S).exponential_(1)}
+        meta = dict(loss=lname, kind=kind, S=S, B=B, D=D, t_func=cfg.model.t_func, max_t=cfg.training.max_t,
+                    n_iter=state["n_iter"], n_iters=cfg.training.n_iters, theta=1.5,
+                    **{k: cfg.loss[k] for k in ("eps_ratio", "nll_weight", "min_time", "one_forward_pass", "logit_type", "loss_type", "ce_coeff")})
+        arrs[f"{tag}__meta"] = np.array(repr(meta))
+        arrs.update({f"{tag}__x0": x0, f"{tag}__u": u, f"{tag}__ts": ts, f"{tag}__E_xt": E_xt, f"{tag}__loss": val.detach(),
+                     f"{tag}__grad": grad, **{f"{tag}__{k}": v for k, v in extra.items()}})
+        arrs[f"{tag}__x_first"] = model.calls[0][0]
+        model.__class__.__call__ = base_call
+    save("losses", **arrs)
+
+
 GROUPS = {"forward_process": gen_forward_process, "noising": gen_noising, "rates": gen_rates,
-          "samplers": gen_samplers, "unet": gen_unet}
+          "samplers": gen_samplers, "unet": gen_unet, "losses": gen_losses}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -1,0 +1,115 @@
+"""GPU: the product losses (lib.losses.losses: HIP noising + device objectives) against the oracle.
+(a) objective parity on identical noise (test hook _FIXED_NOISE) incl. the gradient w.r.t. a scalar
+    model parameter; (b) the HIP noising path inside calc_loss: finite, autograd-connected, and the
+    mean loss over seeds agrees with the oracle's mean over its own draws."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_golden import ThetaToy, _loss_cases, make_process, oracle_loss_from_golden
+
+T = torch.from_numpy
+GAUSS = dict(rate_sigma=6.0, Q_sigma=512.0, time_exp=100.0, time_base=3.0)
+
+
+class DeviceThetaToy:
+    def __init__(self, kind, S, t_func, theta):
+        from ctdd.process import DeviceForwardProcess
+        from oracle.toy_model import toy_logits
+        p = GAUSS if kind == "gaussian" else dict(rate_const=1.7, t_func=t_func)
+        self.process = DeviceForwardProcess(kind, S, "cuda", **p)
+        self.S, self.device, self.f = S, torch.device("cuda"), toy_logits
+        self.theta = torch.tensor(float(theta), device="cuda", requires_grad=True)
+
+    def __call__(self, x, t, *a):
+        return self.f(x, t, self.S, 1.0) * self.theta
+
+    def transition(self, t):
+        return self.process.transition(t)
+
+    def rate(self, t):
+        return self.process.rate(t)
+
+
+def _cfg(m):
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    c = get_config()
+    c.data.S, c.model.concat_dim = m["S"], m["D"]
+    c.loss.update(name=m["loss"], eps_ratio=m["eps_ratio"], nll_weight=m["nll_weight"], min_time=m["min_time"],
+                  one_forward_pass=m["one_forward_pass"], logit_type=m["logit_type"], loss_type=m["loss_type"],
+                  ce_coeff=m["ce_coeff"])
+    c.training.max_t, c.training.n_iters = m["max_t"], m["n_iters"]
+    return c
+
+
+@pytest.mark.parametrize("tag", _loss_cases())
+def test_objective_matches_oracle_on_identical_noise(golden, tag):
+    import lib.losses.losses as L
+    import lib.losses.losses_utils as lu
+    g = golden("losses")
+    fac = lambda kind, S, tf, th: ThetaToy(make_process(kind, S, tf), S, th)
+    m, ts, x_t, x_tilde, omodel, oval = oracle_loss_from_golden(g, tag, fac)
+    ograd, = torch.autograd.grad(oval, omodel.theta)
+    model = DeviceThetaToy(m["kind"], m["S"], m["t_func"], m["theta"])
+    loss = lu.get_loss(_cfg(m))
+    L._FIXED_NOISE = {"ts": ts, "x_t": x_t, "x_tilde": x_tilde if x_tilde is not None else x_t}
+    try:
+        state = {"model": model, "n_iter": m["n_iter"]}
+        x0 = T(g[f"{tag}__x0"]).cuda()
+        val = loss.calc_loss(x0, state) if m["loss"] in ("CatRMNLL", "ScoreElbo") else loss.calc_loss(state, x0)
+        grad, = torch.autograd.grad(val, model.theta)
+    finally:
+        L._FIXED_NOISE = None
+    # same tables on both sides would make this ~1e-6; the GPU builds q_{t|0} itself (K1), rtol 2e-4
+    np.testing.assert_allclose(val.item(), oval.item(), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(grad.item(), ograd.item(), rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(val.item(), float(g[f"{tag}__loss"]), rtol=3e-4, atol=1e-6)   # = the reference's value
+
+
+@pytest.mark.parametrize("tag", ["ctelbo_g16", "catrm_v3_rm", "score_v3", "catrmnll_v2"])
+def test_hip_noising_inside_loss(golden, tag):
+    import lib.losses.losses_utils as lu
+    import lib.losses.losses  # noqa: F401
+    g = golden("losses")
+    m = ast.literal_eval(str(g[f"{tag}__meta"]))
+    model = DeviceThetaToy(m["kind"], m["S"], m["t_func"], m["theta"])
+    loss = lu.get_loss(_cfg(m))
+    x0 = T(g[f"{tag}__x0"]).cuda().repeat(64, 1)            # bigger batch: tighter mean
+    vals = []
+    for seed in range(6):
+        torch.manual_seed(seed)
+        state = {"model": model, "n_iter": m["n_iter"]}
+        v = loss.calc_loss(x0, state) if m["loss"] in ("CatRMNLL", "ScoreElbo") else loss.calc_loss(state, x0)
+        assert torch.isfinite(v) and v.requires_grad
+        vals.append(v.item())
+    # oracle mean over its own draws (torch CPU RNG), same batch
+    from oracle import ctmc_ops as ops, losses as ol
+    proc = make_process(m["kind"], m["S"], m["t_func"])
+    om = ThetaToy(proc, m["S"], m["theta"])
+    ovals = []
+    x0c = x0.cpu()
+    B, D = x0c.shape
+    for seed in range(6):
+        torch.manual_seed(100 + seed)
+        hi = m["max_t"] if m["loss"] in ("CTElbo", "CatRMNLL") else 1.0
+        ts = torch.rand(B) * (hi - m["min_time"]) + m["min_time"]
+        if m["loss"] in ("CatRM", "ScoreElbo"):
+            ts = ts.clamp(max=0.99999)
+        qt0, rate = proc.transition(ts), proc.rate(ts)
+        x_t = ops.noise_xt(qt0, x0c, torch.empty(B * D, m["S"]).exponential_(1))
+        if m["loss"] in ("CTElbo", "ScoreElbo"):
+            _, _, xtl = ops.xtilde_sample(rate, x_t, torch.empty(B, D).exponential_(1), torch.empty(B, m["S"]).exponential_(1))
+        if m["loss"] == "CTElbo":
+            ov = ol.ct_elbo_family("CTElbo", om, x0c, ts, x_t, xtl, eps=m["eps_ratio"], nll_weight=m["nll_weight"], one_forward_pass=m["one_forward_pass"])
+        elif m["loss"] == "ScoreElbo":
+            ov = ol.score_elbo(om, x0c, ts, x_t, xtl, logit_type=m["logit_type"], eps=m["eps_ratio"], nll_weight=m["nll_weight"], one_forward_pass=m["one_forward_pass"])
+        else:
+            ov = ol.crm_family(m["loss"], om, x0c, ts, x_t, S=m["S"], logit_type=m["logit_type"], loss_type=m["loss_type"], ce_coeff=m["ce_coeff"], nll_weight=m["nll_weight"])
+        ovals.append(ov.item())
+    a, b = np.array(vals), np.array(ovals)
+    se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b)) + 1e-9
+    assert abs(a.mean() - b.mean()) < 6 * se + 0.02 * abs(b.mean()), (a, b)

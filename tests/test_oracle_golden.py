@@ -171,3 +171,87 @@ def test_unet_oracle_matches_reference(golden, tag):
     got = nets.image_model_forward(sd, x, t, **cfg)
     np.testing.assert_allclose(got.numpy(), out, rtol=0, atol=1e-4)       # BASELINE bar: logits within 1e-4 fp32
     assert np.abs(out).max() > 1.0                                          # non-degenerate fixture
+
+
+# ------------------------------------------------------------------ P7 (losses)
+def _loss_cases():
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "losses.npz")
+    return sorted(k[: -len("__meta")] for k in np.load(path).files if k.endswith("__meta"))
+
+
+def oracle_loss_from_golden(g, tag, model_factory):
+    """Rebuild the reference's noise draw from the stored E noise and evaluate the oracle loss.
+    model_factory(kind, S, t_func) -> (model object with transition/rate, call(x,t)->logits)."""
+    from oracle import losses as ol
+    m = ast.literal_eval(str(g[f"{tag}__meta"]))
+    S, B, D = m["S"], m["B"], m["D"]
+    x0, u = T(g[f"{tag}__x0"]), T(g[f"{tag}__u"])
+    name = m["loss"]
+    hi = m["max_t"] if name in ("CTElbo", "NLL", "CTElboLambda", "CatRMNLL") else 1.0
+    ts = u * (hi - m["min_time"]) + m["min_time"]
+    if name in ("CatRM", "ScoreElbo"):
+        ts = torch.clamp(ts, max=0.99999)
+    model = model_factory(m["kind"], S, m["t_func"], m["theta"])
+    qt0, rate = model.transition(ts), model.rate(ts)
+    if name == "ScoreElbo":             # Categorical(probs=rows): rows / rowsum
+        rows = qt0[torch.arange(B).view(B, 1), x0.long()].reshape(B * D, S)
+        x_t = ops.exp_race_argmax(rows / rows.sum(-1, keepdim=True), T(g[f"{tag}__E_xt"])).view(B, D)
+    else:
+        x_t = ops.noise_xt(qt0, x0, T(g[f"{tag}__E_xt"]))
+    x_tilde = None
+    if f"{tag}__E_dim" in g:
+        if name == "ScoreElbo":         # probs given directly (no log / -1e9 floor)
+            rv = ops.zero_own_state(rate[torch.arange(B).view(B, 1), x_t.long()], x_t)
+            ds = rv.sum(2)
+            dims = ops.exp_race_argmax(ds / ds.sum(-1, keepdim=True), T(g[f"{tag}__E_dim"]))
+            newp = rv[torch.arange(B), dims]
+            newval = ops.exp_race_argmax(newp / newp.sum(-1, keepdim=True), T(g[f"{tag}__E_val"]))
+            x_tilde = x_t.clone()
+            x_tilde[torch.arange(B), dims] = newval
+        else:
+            _, _, x_tilde = ops.xtilde_sample(rate, x_t, T(g[f"{tag}__E_dim"]), T(g[f"{tag}__E_val"]))
+    if name in ("CTElbo", "NLL", "CTElboLambda"):
+        val = ol.ct_elbo_family(name, model, x0, ts, x_t, x_tilde, eps=m["eps_ratio"], nll_weight=m["nll_weight"],
+                                one_forward_pass=m["one_forward_pass"], weight=m["n_iter"] / m["n_iters"])
+    elif name in ("CatRM", "CatRMNLL", "NLLOriginal"):
+        val = ol.crm_family(name, model, x0, ts, x_t, S=S, logit_type=m["logit_type"], loss_type=m["loss_type"],
+                            ce_coeff=m["ce_coeff"], nll_weight=m["nll_weight"])
+    else:
+        val = ol.score_elbo(model, x0, ts, x_t, x_tilde, logit_type=m["logit_type"], eps=m["eps_ratio"],
+                            nll_weight=m["nll_weight"], one_forward_pass=m["one_forward_pass"])
+    return m, ts, x_t, x_tilde, model, val
+
+
+class ThetaToy:
+    """toy score function scaled by a differentiable theta (the golden generator's model)."""
+
+    def __init__(self, proc, S, theta):
+        from oracle.toy_model import toy_logits
+        self.proc, self.S, self.f = proc, S, toy_logits
+        self.theta = torch.tensor(float(theta), requires_grad=True)
+        self.first = None
+
+    def __call__(self, x, t, *a):
+        if self.first is None:
+            self.first = x.clone()
+        return self.f(x, t, self.S, 1.0) * self.theta
+
+    def transition(self, t):
+        return self.proc.transition(t)
+
+    def rate(self, t):
+        return self.proc.rate(t)
+
+
+@pytest.mark.parametrize("tag", _loss_cases())
+def test_losses_match_reference(golden, tag):
+    g = golden("losses")
+    fac = lambda kind, S, tf, th: ThetaToy(make_process(kind, S, tf), S, th)
+    m, ts, x_t, x_tilde, model, val = oracle_loss_from_golden(g, tag, fac)
+    np.testing.assert_allclose(ts.numpy(), g[f"{tag}__ts"], rtol=0, atol=0)
+    assert torch.equal(model.first.long(), T(g[f"{tag}__x_first"]).long()), "noised state fed to the network must replay exactly"
+    np.testing.assert_allclose(val.item(), float(g[f"{tag}__loss"]), rtol=2e-5)
+    grad, = torch.autograd.grad(val, model.theta)
+    # gradient through (B,D,S)x(S,S) fp32 contractions with ~1e9 dynamic range at S=256: 1e-3
+    np.testing.assert_allclose(grad.item(), float(g[f"{tag}__grad"]), rtol=1e-3, atol=1e-6)
