@@ -346,8 +346,46 @@ def gen_losses():
     save("losses", **arrs)
 
 
+# ------------------------------------------------------------------------------------ P8 (hollow transformer)
+def gen_hollow():
+    """Tiny reference hollow transformers (S=3 maze-like and S=2 synthetic-like), re-drawn weights."""
+    import lib.models.models  # noqa: F401
+    arrs = {}
+    for tag, S, D, E, layers, mlp, mname, tf in (("s3", 3, 12, 32, 2, 48, "UniVarHollowEMA", "sqrt_cos"),
+                                                  ("s2", 2, 16, 16, 1, 32, "UniVarHollowEMA", "log_sqr")):
+        cfg = base_cfg(S, D, mname)
+        cfg.model.update(dict(t_func=tf, net_arch="bidir_transformer", nets="bidir_transformer2", use_cat=False,
+                              embed_dim=E, bidir_readout="attention", use_one_hot_input=False, dropout_rate=0.1,
+                              num_layers=layers, num_heads=4, attention_dropout_rate=0.1, transformer_norm_type="prenorm",
+                              mlp_dim=mlp, out_dim=None, readout_dim=S, num_output_ffresiduals=2, qkv_dim=E,
+                              ema_decay=0.999, time_scale_factor=1000, is_ebm=False))
+        torch.manual_seed(21)
+        model = ref_mu.create_model(cfg, torch.device("cpu"))
+        g = torch.Generator().manual_seed(22)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if p.dim() > 1:
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.0 / math.sqrt(p.shape[-1])))
+                elif "norm" in name and name.endswith("weight") or ".ln" in name and name.endswith("weight") or "resid_layers.1.weight" in name or "resid_layers.3.weight" in name:
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        model.init_ema()
+        model.eval()
+        x = torch.randint(0, S, (3, D), generator=g)
+        t = torch.tensor([0.05, 0.5, 0.97])
+        with torch.no_grad():
+            out = model(x, t)
+        sd = {k: v for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+        arrs.update({f"{tag}__x": x, f"{tag}__t": t, f"{tag}__out": out})
+        arrs.update({f"{tag}__sd__{k}": v for k, v in sd.items()})
+        arrs[f"{tag}__cfg"] = np.array(repr(dict(S=S, D=D, embed_dim=E, num_layers=layers, num_heads=4, mlp_dim=mlp,
+                                                 time_scale_factor=1000, t_func=tf)))
+    save("hollow", **arrs)
+
+
 GROUPS = {"forward_process": gen_forward_process, "noising": gen_noising, "rates": gen_rates,
-          "samplers": gen_samplers, "unet": gen_unet, "losses": gen_losses}
+          "samplers": gen_samplers, "unet": gen_unet, "losses": gen_losses, "hollow": gen_hollow}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GROUPS)

@@ -123,3 +123,94 @@ def image_model_forward(sd, x, t, *, data_shape, S, model_output, fix_logistic=F
     if model_output == "logits":
         return out.reshape(B, C * H * W, S)
     return logistic_logits(out[0], out[1], S, fix_logistic).reshape(B, C * H * W, S)
+
+
+# =========================================================================== hollow transformer
+def _ln(x, sd, key):
+    return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], 1e-5)
+
+
+def _mha(x, sd, pre, heads, mask):
+    """nn.MultiheadAttention(batch_first) self-attention with an additive (L,L) mask, eval mode."""
+    B, L, E = x.shape
+    qkv = F.linear(x, sd[pre + ".in_proj_weight"], sd[pre + ".in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    hd = E // heads
+    sh = lambda z: z.view(B, L, heads, hd).transpose(1, 2)
+    w = torch.softmax(sh(q) @ sh(k).transpose(-1, -2) / math.sqrt(hd) + mask, dim=-1)
+    o = (w @ sh(v)).transpose(1, 2).reshape(B, L, E)
+    return F.linear(o, sd[pre + ".out_proj.weight"], sd[pre + ".out_proj.bias"])
+
+
+def _positional(L, E):
+    pos = torch.arange(L).unsqueeze(1)
+    div = torch.exp(torch.arange(0, E, 2) * (-math.log(10000.0) / E))
+    pe = torch.zeros(L, E)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+def _unidir(x_embed, temb, sd, pre, direction, layers, heads):
+    """UniDirectionalTransformer.forward (hollow_networks.py:520-568), prenorm, eval mode."""
+    B, D, E = x_embed.shape
+    t = temb.unsqueeze(1)
+    if direction == "l2r":
+        x = torch.cat([t, x_embed[:, :-1]], dim=1)
+        blocked = torch.triu(torch.ones(D, D, dtype=torch.bool), diagonal=1)
+    else:
+        x = torch.cat([x_embed[:, 1:], t], dim=1)
+        blocked = torch.tril(torch.ones(D, D, dtype=torch.bool), diagonal=-1)
+    mask = torch.zeros(D, D).masked_fill(blocked, float("-inf"))
+    x = x + _positional(D, E)
+    for i in range(layers):
+        b = f"{pre}.trans_block_layers.{i}"
+        x = x + _mha(_ln(x, sd, b + ".self_attention_block.norm"), sd, b + ".self_attention_block.self_attention", heads, mask)
+        z = _ln(x, sd, b + ".feed_forward_block.norm")
+        z = F.linear(F.relu(F.linear(z, sd[b + ".feed_forward_block.mlp.fc1.weight"], sd[b + ".feed_forward_block.mlp.fc1.bias"])),
+                     sd[b + ".feed_forward_block.mlp.fc2.weight"])
+        x = x + z
+    return x
+
+
+def hollow_forward(sd, x, t, *, S, embed_dim, num_layers, num_heads, time_scale_factor, num_output_ffresiduals=2,
+                   prefix="net."):
+    """BidirectionalTransformer2.forward (hollow_networks.py:726-755) with use_cat=False, prenorm,
+    attention readout (CrossAttention 204-280 + ResidualReadout 90-132); dropout off."""
+    sd = {k[len(prefix):]: v for k, v in sd.items() if isinstance(v, torch.Tensor) and k.startswith(prefix)}
+    E, B, D = embed_dim, x.shape[0], x.shape[1]
+    half = E // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    arg = (t.float() * time_scale_factor)[:, None] * freq[None, :]
+    temb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+    xn = (x.float() / (S - 1)) * 2 - 1
+    x_embed = F.linear(xn.view(B, D, 1), sd["input_embedding.weight"], sd["input_embedding.bias"])
+    l2r = _unidir(x_embed, temb, sd, "module_l2r", "l2r", num_layers, num_heads)
+    r2l = _unidir(x_embed, temb, sd, "module_r2l", "r2l", num_layers, num_heads)
+    # attention readout
+    ro = "readout_module"
+    inputs = l2r + r2l
+    a, b = _ln(l2r, sd, ro + ".ln1"), _ln(r2l, sd, ro + ".ln2")
+    H = num_heads
+    hd = E // H
+    allk = torch.cat([temb.unsqueeze(1), a, b], dim=1)
+    q = F.linear(a + b, sd[ro + ".cross_attention.dense_query.weight"]).view(B, D, H, hd) / math.sqrt(hd)
+    k = F.linear(allk, sd[ro + ".cross_attention.dense_key.weight"], sd[ro + ".cross_attention.dense_key.bias"]).view(B, 2 * D + 1, H, hd)
+    v = F.linear(allk, sd[ro + ".cross_attention.dense_val.weight"], sd[ro + ".cross_attention.dense_val.bias"]).view(B, 2 * D + 1, H, hd)
+    logits = torch.einsum("bqhd,bkhd->bhqk", q, k)
+    ones = torch.ones(D, D, dtype=torch.bool)
+    allow = torch.cat([torch.ones(D, 1, dtype=torch.bool), torch.tril(ones), torch.triu(ones)], dim=-1)
+    w = torch.softmax(torch.where(allow.view(1, 1, D, -1), logits, torch.tensor(torch.finfo(torch.float32).min)), dim=-1)
+    att = torch.einsum("bhqk,bkhd->bqhd", w, v).reshape(B, D, H * hd)
+    z = F.linear(att, sd[ro + ".cross_attention.out_linear.weight"], sd[ro + ".cross_attention.out_linear.bias"]) + inputs
+    # residual readout with FiLM
+    m = ro + ".model"
+    lin = lambda u, key: F.linear(u, sd[key + ".weight"], sd[key + ".bias"])
+    tt = lin(F.gelu(lin(temb, m + ".mlp.layers.0")), m + ".mlp.layers.2")
+    z = lin(z, m + ".input_layer")
+    for i in range(num_output_ffresiduals):
+        r = lin(F.gelu(lin(z, f"{m}.resid_layers.{2 * i}.layers.0")), f"{m}.resid_layers.{2 * i}.layers.2")
+        z = _ln(z + r, sd, f"{m}.resid_layers.{2 * i + 1}")
+        fa, fb = torch.chunk(lin(tt, f"{m}.film_layer.{i}").unsqueeze(1), 2, dim=-1)
+        z = fa * z + fb
+    return lin(z, m + ".logits_layer")

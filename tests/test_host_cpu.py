@@ -1,0 +1,249 @@
+"""CPU: host-side logic of the drop-in boundary (no kernels run): registries, configs, model
+construction (exact reference parameter counts and state-dict names), EMA semantics, the train
+step's argument orders and NaN guard, time grids, the rate-matrix construction, the distributed
+sample sharder (gloo, world size 2)."""
+import ast
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+T = torch.from_numpy
+
+
+def _load_lib():
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.sampling.sampling  # noqa: F401
+    import lib.sampling.sampling_utils as su
+    import lib.losses.losses  # noqa: F401
+    import lib.losses.losses_utils as lu
+    import lib.training.training  # noqa: F401
+    import lib.training.training_utils as tu
+    import lib.optimizers.optimizers  # noqa: F401
+    import lib.optimizers.optimizers_utils as ou
+    return mu, su, lu, tu, ou
+
+
+def test_registries_and_aliases():
+    mu, su, lu, tu, ou = _load_lib()
+    for name in ("GaussianTargetRateImageX0PredEMAPaul", "GaussianHollowEMA", "UniVarHollowEMA", "UniformRateUnetEMA", "UniVarUnetEMA"):
+        assert mu.get_model(name).__name__ == name
+    for name in ("TauL", "LBJF", "MidPointTauL", "PCTauL", "CRMLBJF", "ElboTauL", "TauLeaping", "LBJFSampling"):
+        assert name in su._SAMPLERS
+    for name in ("CTElbo", "NLL", "CTElboLambda", "CatRM", "CatRMNLL", "NLLOriginal", "ScoreElbo"):
+        assert name in lu._LOSSES
+    assert "Standard" in tu._TRAINSTEPS and "Adam" in ou._OPTIMIZERS
+    with pytest.raises(ValueError):
+        su.register_sampler(su._SAMPLERS["TauL"])          # duplicate class name
+    with pytest.raises(KeyError):
+        mu.get_model("NoSuchModel")
+
+
+@pytest.mark.parametrize("mod,n_params", [("mnist_config.config_tauUnet_mnist", 14017696),
+                                          ("mnist_config.config_hollow_mnist", 14082304),
+                                          ("maze_config.config_hollow_maze", 7808643),
+                                          ("synthetic_config.config_hollow_synthetic", 596610)])
+def test_configs_build_reference_sized_models(mod, n_params):
+    import importlib
+    mu = _load_lib()[0]
+    cfg = importlib.import_module("config." + mod).get_config()
+    cfg.device = "cpu"
+    model = mu.create_model(cfg, torch.device("cpu"))
+    assert sum(p.numel() for p in model.parameters()) == n_params       # SURVEY: probed reference counts
+    sd = model.state_dict()
+    assert {"ema_decay", "ema_num_updates", "ema_shadow_params"} <= set(sd)
+    for sec in ("loss", "training", "data", "model", "optimizer", "saving", "sampler"):
+        assert sec in cfg
+    assert cfg.model.concat_dim == int(np.prod(cfg.data.shape))
+
+
+def test_cifar_config_fields():
+    from config.cifar10_config.config_tauUnet_cifar10 import get_config
+    c = get_config()
+    assert (c.data.S, c.model.concat_dim, c.model.model_output, c.loss.name) == (256, 3072, "logistic_pars", "CTElboLambda")
+    assert c.model.ch == 128 and list(c.model.ch_mult) == [1, 2, 2, 2]
+
+
+def test_modules_load_reference_state_dicts_and_match_golden(golden):
+    """The product module trees carry the reference's parameter names: reference-format state dicts
+    load strictly and (on the CPU, plain autograd ops) reproduce the reference logits."""
+    mu = _load_lib()[0]
+    from config.mnist_config.config_tauUnet_mnist import get_config as unet_cfg
+    from config.maze_config.config_hollow_maze import get_config as hollow_cfg
+    g = golden("unet")
+    for tag in ("logits", "logistic"):
+        meta = ast.literal_eval(str(g[f"{tag}__cfg"]))
+        cfg = unet_cfg()
+        cfg.device = "cpu"
+        C, H, W = meta["data_shape"]
+        cfg.data.S, cfg.data.image_size, cfg.data.shape = meta["S"], H, [C, H, W]
+        cfg.model.update(ch=meta["ch"], ch_mult=meta["ch_mult"], num_res_blocks=1, num_heads=meta["num_heads"],
+                         input_channels=C, data_min_max=meta["x_min_max"], model_output=meta["model_output"],
+                         attn_resolutions=[int(meta["ch"] / 2)], concat_dim=C * H * W)
+        model = mu.create_model(cfg, torch.device("cpu"))
+        pre = f"{tag}__sd__"
+        sd = {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+        missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+        assert not missing and not unexpected
+        model.init_ema()
+        model.eval()
+        with torch.no_grad():
+            out = model(T(g[f"{tag}__x"]), T(g[f"{tag}__t"]))
+        np.testing.assert_allclose(out.numpy(), g[f"{tag}__out"], rtol=0, atol=1e-4)
+    g = golden("hollow")
+    for tag in ("s3", "s2"):
+        meta = ast.literal_eval(str(g[f"{tag}__cfg"]))
+        cfg = hollow_cfg()
+        cfg.device = "cpu"
+        cfg.data.S = meta["S"]
+        cfg.model.update(concat_dim=meta["D"], embed_dim=meta["embed_dim"], num_layers=meta["num_layers"], num_heads=meta["num_heads"],
+                         mlp_dim=meta["mlp_dim"], qkv_dim=meta["embed_dim"], readout_dim=meta["S"], t_func=meta["t_func"])
+        model = mu.create_model(cfg, torch.device("cpu"))
+        pre = f"{tag}__sd__"
+        sd = {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+        missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+        assert not missing and not unexpected
+        model.init_ema()
+        model.eval()
+        with torch.no_grad():
+            out = model(T(g[f"{tag}__x"]), T(g[f"{tag}__t"]))
+        np.testing.assert_allclose(out.numpy(), g[f"{tag}__out"], rtol=0, atol=1e-4)
+
+
+def test_ema_semantics():
+    mu = _load_lib()[0]
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    cfg = get_config()
+    cfg.device = "cpu"
+    model = mu.create_model(cfg, torch.device("cpu"))
+    p0 = [p.detach().clone() for p in model.parameters()]
+    with pytest.raises(ValueError):
+        model.train()                                      # already in train mode
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+    model.update_ema()                                     # decay = min(0.9999, 2/11)
+    d = 2.0 / 11.0
+    exp0 = p0[0] + (1 - d) * 1.0
+    assert torch.allclose(model.shadow_params[0], exp0, atol=1e-6) and model.num_updates == 1
+    live = [p.detach().clone() for p in model.parameters()]
+    model.eval()                                           # shadow -> live
+    assert torch.allclose(next(model.parameters()), exp0, atol=1e-6)
+    with pytest.raises(ValueError):
+        model.eval()
+    model.train()                                          # live restored
+    assert torch.equal(next(model.parameters()), live[0])
+    sd = model.state_dict()
+    assert sd["ema_num_updates"] == 1 and len(sd["ema_shadow_params"]) == len(p0)
+    model.load_state_dict(sd)
+    bad = dict(sd)
+    bad.pop("ema_decay")
+    with pytest.raises(ValueError):
+        model.load_state_dict(bad)
+
+
+class _DummyLoss:
+    def __init__(self, nan=False):
+        self.nan = nan
+
+    def calc_loss(self, state, minibatch, label=None):
+        w = next(state["model"].parameters())
+        v = (w.float() ** 2).mean() + minibatch.float().mean() * 0
+        return v * float("nan") if self.nan else v
+
+
+class _OldOrderLoss:
+    def calc_loss(self, minibatch, state):
+        return (next(state["model"].parameters()).float() ** 2).mean()
+
+
+def test_train_step_orders_and_nan_guard():
+    mu, _, _, tu, ou = _load_lib()
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    cfg = get_config()
+    cfg.device = "cpu"
+    model = mu.create_model(cfg, torch.device("cpu"))
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+    step = tu.get_train_step(cfg)
+    mb = torch.zeros(4, 32, dtype=torch.long)
+    w0 = next(model.parameters()).detach().clone()
+    l1 = step.step(state, _DummyLoss(), mb)                # train_image.py order
+    assert l1.dim() == 0 and not l1.requires_grad and model.num_updates == 1
+    assert not torch.equal(next(model.parameters()), w0)
+    step.step(state, mb, _DummyLoss())                     # stale order of train_synthetic.py:103
+    step.step(state, _OldOrderLoss(), mb)                  # (minibatch, state) loss signature
+    assert model.num_updates == 3
+    w1 = next(model.parameters()).detach().clone()
+    out = step.step(state, _DummyLoss(nan=True), mb)       # NaN guard: no update, returns 1e9
+    assert float(out) == 1e9 and torch.equal(next(model.parameters()), w1) and model.num_updates == 3
+
+
+def test_host_rate_matrix_and_time_grids_match_oracle():
+    from ctdd.process import gaussian_target_rate_matrix, uniform_rate_matrix, birth_death_rate_matrix
+    from oracle import forward_process as ofp, ctmc_ops as ops
+    for S in (8, 33, 256):
+        assert np.array_equal(gaussian_target_rate_matrix(S, 6.0, 512.0), ofp.gaussian_target_rate_matrix(S, 6.0, 512.0))
+    assert np.array_equal(uniform_rate_matrix(3, 1.7), ofp.uniform_rate_matrix(3, 1.7))
+    assert np.array_equal(birth_death_rate_matrix(8), ofp.birth_death_rate_matrix(8))
+    ts = ops.taul_time_grid(1.0, 0.01, 1000)
+    assert len(ts) == 1001 and ts[0] == 1.0 and ts[-2] == 0.01 and ts[-1] == 0.0
+
+
+def test_kernels_are_not_reachable_on_cpu():
+    """No CPU fallback: the device process refuses to build tables from CPU tensors."""
+    from ctdd import native
+    from ctdd.process import DeviceForwardProcess
+    pr = DeviceForwardProcess("uniform", 3, "cpu", rate_const=1.0)
+    with pytest.raises(native.CtddError):
+        pr.transition(torch.tensor([0.5]))
+
+
+# ------------------------------------------------------------------ multi-process sharding (gloo, CPU)
+class _StubSampler:
+    """Stands in for a sampler: deterministic per-(key, row) output so the gather can be checked."""
+    D = 5
+    rank_stream = 0
+
+    def sample(self, model, n):
+        rows = np.arange(n)[:, None] * 10 + np.arange(self.D)[None, :] + 1000 * self.rank_stream
+        return rows.astype(int), [float(self.rank_stream)]
+
+
+def _worker(rank, world, port, n_total, q):
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "continuous-time-diffusion-models-for-discrete-data_amd")]
+    from ctdd.distributed import sample_sharded
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    full, extra = sample_sharded(_StubSampler(), None, n_total)
+    q.put((rank, full.tolist(), extra))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_sharding_world2_gloo():
+    from ctdd.distributed import shard_counts, shard_offsets
+    assert shard_counts(7, 2) == [4, 3] and shard_offsets(7, 2) == [0, 4] and shard_counts(3, 4) == [1, 1, 1, 0]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = np.concatenate([np.arange(4)[:, None] * 10 + np.arange(5)[None, :],
+                          np.arange(3)[:, None] * 10 + np.arange(5)[None, :] + 1000])
+    for rank, full, extra in res:
+        assert np.array_equal(np.asarray(full), exp)       # every rank holds all 7 samples, rank-major
+        assert extra == [float(rank)]

@@ -255,3 +255,21 @@ def test_losses_match_reference(golden, tag):
     grad, = torch.autograd.grad(val, model.theta)
     # gradient through (B,D,S)x(S,S) fp32 contractions with ~1e9 dynamic range at S=256: 1e-3
     np.testing.assert_allclose(grad.item(), float(g[f"{tag}__grad"]), rtol=1e-3, atol=1e-6)
+
+
+# ------------------------------------------------------------------ P8 (hollow transformer)
+def load_hollow_case(g, tag):
+    cfg = ast.literal_eval(str(g[f"{tag}__cfg"]))
+    pre = f"{tag}__sd__"
+    sd = {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+    return cfg, sd, T(g[f"{tag}__x"]), T(g[f"{tag}__t"]), g[f"{tag}__out"]
+
+
+@pytest.mark.parametrize("tag", ["s3", "s2"])
+def test_hollow_oracle_matches_reference(golden, tag):
+    from oracle import nets
+    cfg, sd, x, t, out = load_hollow_case(golden("hollow"), tag)
+    got = nets.hollow_forward(sd, x, t, S=cfg["S"], embed_dim=cfg["embed_dim"], num_layers=cfg["num_layers"],
+                              num_heads=cfg["num_heads"], time_scale_factor=cfg["time_scale_factor"])
+    np.testing.assert_allclose(got.numpy(), out, rtol=0, atol=1e-4)
+    assert np.abs(out).max() > 0.5
