@@ -199,6 +199,8 @@ def gen_samplers():
         ("midpoint_v3_ord", "MidPointTauL", "univar", 3, 15, 8, dict(loss="CTElbo", is_ordinal=True, initial_dist="uniform", max_t=0.99999, data_name="Maze3S", scale=3.0)),
         ("midpoint_v2", "MidPointTauL", "univar", 2, 32, 8, dict(loss="CatRMNLL", logit_type="direct", is_ordinal=False, initial_dist="uniform", max_t=0.99999, t_func="log_sqr", data_name="SyntheticData")),
         ("pctaul_g16", "PCTauL", "gaussian", 16, 12, 6, dict(corrector_entry_time=0.7, num_corrector_steps=2, num_steps=8)),
+        ("exact_v3", "ExactSampling", "univar", 3, 15, 8, dict(loss="CatRM", initial_dist="uniform", max_t=0.99999)),
+        ("exact_u3", "ExactSampling", "uniform", 3, 9, 6, dict(loss="CatRM", initial_dist="uniform", max_t=0.99999)),
     ]
     for tag, sname, kind, S, D, N, ov in runs:
         cfg = base_cfg(S, D)

@@ -172,3 +172,24 @@ def pctaul_sample(model, N, D, S, *, min_t, num_steps, initial_dist, eps_ratio,
                 x = ops.tauleap_apply(x, _poisson(corr * (corrector_step_size_multiplier * h)), True)
     p = F.softmax(model(x, min_t * torch.ones((N,))), dim=2)
     return torch.max(p, dim=2)[1].numpy().astype(int)
+
+
+def exact_sample(model, N, D, S, *, max_t, min_t, num_steps, initial_dist, init_std, x_init=None):
+    """ExactSampling.sample (sampling.py:990-1061, log_prob == 'cat'): per step
+    x_new^d ~ Categorical(logits = logsumexp_x0(log p0t[x0] + log(q_{t-h|0}[x0,s] q_{t|t-h}[s,x_t])))."""
+    x = initial_samples(N, D, S, initial_dist, init_std) if x_init is None else x_init.clone()
+    ts = ops.taul_time_grid(max_t, min_t, num_steps)
+    change = []
+    for idx, t in enumerate(ts[:-1]):
+        h = ts[idx] - ts[idx + 1]
+        t_ones = t * torch.ones((N,))
+        log_p0t = F.log_softmax(model(x, t_ones), dim=2)
+        t_eps = t - h
+        q_teps_0 = model.transition(t_eps * torch.ones((N,))).unsqueeze(1)                  # N,1,S,S
+        q_t_teps = model.transit_between(t_eps * torch.ones((N,)), t_ones).permute(0, 2, 1)  # [n, x_t, s]
+        q_t_teps = q_t_teps[torch.arange(N).view(N, 1), x.long()].unsqueeze(-2)             # N,D,1,S
+        log_prob = torch.logsumexp(log_p0t.unsqueeze(-1) + torch.log(q_teps_0 * q_t_teps), dim=-2).view(-1, S)
+        x_new = _categorical_rows(ops.categorical_probs_from_logits(log_prob)).view(N, D)
+        change.append((torch.sum(x_new != x) / (N * D)).item())
+        x = x_new
+    return x.numpy().astype(int), change

@@ -64,7 +64,7 @@ def _two_sample_chi2(a, b, S):
 
 
 @pytest.mark.parametrize("case", ["taul_ord", "taul_nonord", "taul_corr", "taul_crm", "lbjf", "lbjf_crm_corr",
-                                  "midpoint", "pctaul"])
+                                  "midpoint", "pctaul", "exact"])
 def test_sampler_distribution_matches_oracle(case):
     import lib.sampling.sampling  # noqa: F401
     import lib.sampling.sampling_utils as su
@@ -78,6 +78,7 @@ def test_sampler_distribution_matches_oracle(case):
         "lbjf_crm_corr": ("LBJF", "univar", 3, 15, "CatRMNLL", "reverse_logscale", dict(initial_dist="uniform", max_t=0.99999, corrector_entry_time=0.5, num_corrector_steps=1), 3.0),
         "midpoint": ("MidPointTauL", "univar", 3, 15, "CatRM", "reverse_prob", dict(is_ordinal=False, initial_dist="uniform", max_t=0.99999), 3.0),
         "pctaul": ("PCTauL", "gaussian", 16, 10, "CTElbo", "direct", dict(corrector_entry_time=0.7, num_corrector_steps=2, initial_dist="gaussian"), 1.0),
+        "exact": ("ExactSampling", "univar", 3, 15, "CatRM", "direct", dict(initial_dist="uniform", max_t=0.99999), 3.0),
     }[case]
     sname, kind, S, D, loss, lt, over, scale = spec
     params = GAUSS if kind == "gaussian" else dict(rate_const=1.7, t_func="sqrt_cos")
@@ -103,6 +104,9 @@ def test_sampler_distribution_matches_oracle(case):
         ref = osamp.lbjf_sample(om, N, D, S, max_t=cfg.training.max_t, init_std=512.0, loss_name=loss, logit_type=lt,
                                 corrector_entry_time=s.corrector_entry_time, num_corrector_steps=s.num_corrector_steps,
                                 **common)
+    elif sname == "ExactSampling":
+        ref = osamp.exact_sample(om, N, D, S, max_t=cfg.training.max_t, min_t=s.min_t, num_steps=s.num_steps,
+                                 initial_dist=s.initial_dist, init_std=512.0)
     elif sname == "MidPointTauL":
         ref = osamp.midpoint_sample(om, N, D, S, max_t=cfg.training.max_t, init_std=512.0, is_ordinal=s.is_ordinal,
                                     loss_name=loss, logit_type=lt, **common)
@@ -118,6 +122,8 @@ def test_sampler_distribution_matches_oracle(case):
     se = np.sqrt(hip.var(0) / N + ref[0].var(0) / N) + 1e-9
     assert (np.abs(hip.mean(0) - ref[0].mean(0)) / se).max() < 5.5
     # per-step change-rate trajectory (TauL / LBJF return it as 2nd output, MidPoint as 3rd)
+    if sname == "ExactSampling":
+        assert np.abs(np.asarray(out[1]) - np.asarray(ref[1])).max() < 0.03
     if sname in ("TauL", "LBJF"):
         a, b = np.asarray(out[1]), np.asarray(ref[1])
         assert a.shape == b.shape

@@ -247,3 +247,37 @@ def test_sample_sharding_world2_gloo():
     for rank, full, extra in res:
         assert np.array_equal(np.asarray(full), exp)       # every rank holds all 7 samples, rank-major
         assert extra == [float(rank)]
+
+
+def test_bookkeeping_roundtrip(tmp_path):
+    """save_state / load_state / save_config / load_config keep the reference's file layout
+    (<dir>/<date>/model_<n>.pt with the three EMA keys, <dir>/<date>/config_001.yaml)."""
+    import glob
+    mu, _, _, _, ou = _load_lib()
+    import lib.utils.bookkeeping as bk
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    cfg = get_config()
+    cfg.device = "cpu"
+    model = mu.create_model(cfg, torch.device("cpu"))
+    opt = ou.get_optimizer(model.parameters(), cfg)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.5)
+    model.update_ema()
+    state = {"model": model, "optimizer": opt, "n_iter": 41}
+    bk.save_state(state, str(tmp_path))
+    bk.save_config(cfg, str(tmp_path))
+    pt = glob.glob(str(tmp_path / "*" / "model_41.pt"))
+    yml = glob.glob(str(tmp_path / "*" / "config_001.yaml"))
+    assert len(pt) == 1 and len(yml) == 1
+    raw = torch.load(pt[0], map_location="cpu", weights_only=True)
+    assert set(raw) == {"model", "optimizer", "n_iter"} and {"ema_decay", "ema_num_updates", "ema_shadow_params"} <= set(raw["model"])
+    cfg2 = bk.load_config(yml[0])
+    assert cfg2.model.name == cfg.model.name and cfg2.sampler.num_steps == cfg.sampler.num_steps and list(cfg2.data.shape) == [32]
+    model2 = mu.create_model(cfg2, torch.device("cpu"))
+    state2 = {"model": model2, "optimizer": ou.get_optimizer(model2.parameters(), cfg2), "n_iter": 0}
+    state2 = bk.load_state(state2, pt[0], torch.device("cpu"))
+    assert state2["n_iter"] == 41 and model2.num_updates == 1
+    for a, b in zip(model.parameters(), model2.parameters()):
+        assert torch.equal(a, b)
+    assert torch.equal(model.shadow_params[0], model2.shadow_params[0])

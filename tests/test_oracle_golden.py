@@ -146,6 +146,9 @@ def test_sampler_replay_exact(golden, tag):
     elif m["sampler"] == "MidPointTauL":
         out = osamp.midpoint_sample(model, N, D, S, max_t=m["max_t"], init_std=512.0, is_ordinal=m["is_ordinal"],
                                     loss_name=m["loss"], logit_type=m["logit_type"], **common)
+    elif m["sampler"] == "ExactSampling":
+        out = osamp.exact_sample(model, N, D, S, max_t=m["max_t"], min_t=m["min_t"], num_steps=m["num_steps"],
+                                 initial_dist=m["initial_dist"], init_std=512.0)
     else:
         out = (osamp.pctaul_sample(model, N, D, S, corrector_entry_time=m["corrector_entry_time"],
                                    num_corrector_steps=m["num_corrector_steps"],
