@@ -85,7 +85,7 @@ def kernel_roofline(sampler, st, steps, batch):
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch}
 
 
-def cpu_baseline(model_gpu, cfg, batch, budget_s=20.0):
+def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
     """The CPU oracle (restatement of the reference's CPU path, pinned by tests/golden) doing the
     same tau-leaping step on the host cores: oracle U-Net forward + reverse rates + torch.poisson
     + update.  Bounded sample: `batch` samples, as many steps as fit in ~budget_s."""
@@ -118,7 +118,7 @@ def cpu_baseline(model_gpu, cfg, batch, budget_s=20.0):
             x = ops.tauleap_apply(x, jumps, cfg.sampler.is_ordinal)
             done += 1
             el = time.perf_counter() - t0
-            if el > budget_s or done >= 50:
+            if el > budget_s or done >= 600:
                 break
     return {"value": round(batch * done / el, 2), "unit": "sample-steps/s", "cores": cores, "kind": "port",
             "sample": f"{done} tau-leaping steps of {batch} samples (oracle U-Net fwd + rates + torch.poisson + update), {el:.1f} s"}

@@ -7,13 +7,14 @@ namespace ctdd {
 constexpr float POISSON_ICDF_MAX_LAMBDA = 12.0f;   // inverse-CDF search up to here, split above
 constexpr int POISSON_ICDF_KMAX = 64;
 // Row rule (superposition of independent Poisson processes, exact in distribution):
-//   Lambda = h * sum_s r_s <= SUPERPOSE_MAX_LAMBDA:  K ~ Poisson(Lambda) from uniform #0 of the row's
-//     stream, then K destinations ~ Categorical(r) by inverse CDF from uniforms #1.. ;
+//   Lambda = h * sum_s r_s <= SUPERPOSE_MAX_LAMBDA:  K ~ Poisson(Lambda) from the first uniform(s) of the
+//     row's stream (Lambda > 12: sum of n = ceil(Lambda/12) draws of Poisson(Lambda/n), one uniform each),
+//     then K destinations ~ Categorical(r) by inverse CDF from the following uniforms;
 //   above: the same one level down -- every sub-block b of 4 consecutive destinations draws
 //     K_b ~ Poisson(h * sum_{s in b} r_s) from uniform (b & 3) of Philox block DENSE_DRAW0 + (b >> 2)
 //     and, if K_b > 0, K_b picks among its 4 destinations from the private stream PICK_DRAW0 + 16 b
 //     (K_b for a rate > 12 is the sum of <= 64 equal parts from the stream SPLIT_DRAW0 + 16 b).
-constexpr float SUPERPOSE_MAX_LAMBDA = 2.0f;
+constexpr float SUPERPOSE_MAX_LAMBDA = 64.0f;
 constexpr uint32_t DENSE_DRAW0 = 1024u;
 constexpr uint32_t SPLIT_DRAW0 = 8192u;
 constexpr uint32_t PICK_DRAW0 = 65536u;
@@ -65,6 +66,16 @@ __device__ inline int poisson_element(float lam, float u, uint64_t seed, uint64_
   PhiloxStream rs(seed, offset, row, SPLIT_DRAW0 + 16u * (uint32_t)s);   // s = sub-block index
   int k = 0;
   for (int i = 0; i < n; ++i) k += poisson_icdf(lc, rs.next());
+  return k;
+}
+
+// K ~ Poisson(Lam), Lam <= SUPERPOSE_MAX_LAMBDA, from the row's stream (see the row rule above)
+__device__ inline int poisson_row(float Lam, PhiloxStream& rng) {
+  if (Lam <= POISSON_ICDF_MAX_LAMBDA) return poisson_icdf(Lam, rng.next());
+  const int n = (int)ceilf(Lam / POISSON_ICDF_MAX_LAMBDA);
+  const float lc = Lam / (float)n;
+  int k = 0;
+  for (int i = 0; i < n; ++i) k += poisson_icdf(lc, rng.next());
   return k;
 }
 

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   int jump = 0;
   if (Lam > 0.0f && Lam <= SUPERPOSE_MAX_LAMBDA) {
     PhiloxStream rng(a.seed, a.offset, (uint64_t)rowc, 0u);   // identical in every lane of the row
-    const int K = poisson_icdf(Lam, rng.next());
+    const int K = poisson_row(Lam, rng);
     if (K > 0 && (ordinal || K == 1)) {
       // inclusive prefix sums of rr in s order (s = li + k*G)
       float c[EPT], carry = 0.0f;

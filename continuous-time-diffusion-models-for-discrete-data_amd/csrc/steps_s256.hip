@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
   int jump = 0;
   if (Lam > 0.0f && Lam <= SUPERPOSE_MAX_LAMBDA) {
     PhiloxStream rng(a.seed, a.offset, rngrow, 0u);             // both lanes of the pair: same stream
-    const int K = poisson_icdf(Lam, rng.next());
+    const int K = poisson_row(Lam, rng);
     if (K > 0 && (ordinal || K == 1)) {
       // cumulative rates in destination order (block of 8 = g0's four then g1's four), written
       // back over the lane's own LDS column; the ends of the lane's 32 blocks stay in registers

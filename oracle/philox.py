@@ -67,7 +67,7 @@ def row_uniforms(rows, offset, seed, ndraw_blocks=1, draw0=0):
 # ------------------------------------------------------------------ draw rules of the kernels
 POISSON_ICDF_MAX_LAMBDA = 12.0   # inverse-CDF search up to here, PTRS above
 POISSON_ICDF_KMAX = 64
-SUPERPOSE_MAX_LAMBDA = 2.0       # rows with total rate*h above this draw every destination independently
+SUPERPOSE_MAX_LAMBDA = 64.0      # rows with total rate*h above this draw per sub-block of 4 destinations
 DENSE_DRAW0 = 1024
 SPLIT_DRAW0 = 8192
 PICK_DRAW0 = 65536
@@ -113,8 +113,9 @@ def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
     rates (N,D,S) float32 reverse rates evaluated at x_base (default x); its own state is masked here.
 
     Row rule: Lambda = h*sum_s r_s.
-      Lambda <= SUPERPOSE_MAX_LAMBDA: K ~ Poisson(Lambda) from uniform #0 of the row's stream, then
-        K destinations by inverse CDF over r in s order from uniforms #1.. ;
+      Lambda <= SUPERPOSE_MAX_LAMBDA: K ~ Poisson(Lambda) from the first uniform(s) of the row's stream
+        (Lambda > 12: n = ceil(Lambda/12) draws of Poisson(Lambda/n), summed), then K destinations by
+        inverse CDF over r in s order from the following uniforms;
       above: the same rule one level down: every sub-block b of 4 consecutive destinations draws
         K_b ~ Poisson(h*sum_{s in b} r_s) from uniform (b&3) of Philox block DENSE_DRAW0 + (b>>2) and
         K_b picks among its destinations from the stream PICK_DRAW0 + 16 b (a rate > 12 is the sum
@@ -137,21 +138,34 @@ def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
     decided = np.ones(N * D, dtype=bool)
     decided &= np.abs(lam - SUPERPOSE_MAX_LAMBDA) > 1e-4       # regime choice itself must be clear
     dense = lam > SUPERPOSE_MAX_LAMBDA
-    # ---- superposition regime
-    nblk = 1 + (POISSON_ICDF_KMAX + 4) // 4
+    # ---- superposition regime: K from the first uniform(s) of the row stream, picks from the next ones
     sp = ~dense & (lam > 0)
     if sp.any():
-        U = row_uniforms(rows[sp], offset, seed, nblk)
-        K, margin = poisson_icdf(lam[sp], U[:, 0])
-        dsp = margin > 1e-5
-        jsp = np.zeros(sp.sum(), dtype=np.int64)
-        rs, bs = r[sp], bf[sp]
-        for j in range(int(K.max()) if K.size else 0):
-            act = K > j
-            idx, mg = categorical_icdf(rs[act], U[act, 1 + j])
-            jsp[act] += idx - bs[act]
+        lam_sp = lam[sp]
+        npart = np.where(lam_sp <= POISSON_ICDF_MAX_LAMBDA, 1, np.ceil(lam_sp / np.float32(POISSON_ICDF_MAX_LAMBDA))).astype(np.int64)
+        lc = (lam_sp / npart.astype(np.float32)).astype(np.float32)
+        nblk = 2 + (int(npart.max()) + 6 * POISSON_ICDF_KMAX) // 4
+        U = row_uniforms(rows[sp], offset, seed, min(nblk, 64))
+        K = np.zeros(lam_sp.shape, dtype=np.int64)
+        dsp = np.ones(lam_sp.shape, dtype=bool)
+        for i in range(int(npart.max())):
+            act = npart > i
+            k_i, mg = poisson_icdf(lc[act], U[act, i])
+            K[act] += k_i
             d = dsp[act]
             d &= mg > 1e-5
+            dsp[act] = d
+        jsp = np.zeros(sp.sum(), dtype=np.int64)
+        rs, bs = r[sp], bf[sp]
+        ridx = np.arange(lam_sp.shape[0])
+        for j in range(int(K.max()) if K.size else 0):
+            act = K > j
+            col = npart[act] + j
+            ok = col < U.shape[1]
+            idx, mg = categorical_icdf(rs[act], U[ridx[act], np.minimum(col, U.shape[1] - 1)])
+            jsp[act] += idx - bs[act]
+            d = dsp[act]
+            d &= (mg > 1e-5) & ok
             dsp[act] = d
         if not is_ordinal:
             jsp = np.where(K > 1, 0, jsp)
