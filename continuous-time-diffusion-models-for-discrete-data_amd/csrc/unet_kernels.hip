@@ -514,43 +514,60 @@ __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
   const int cg = a.Cout / 8, HW = a.H * a.W, b = blockIdx.y;
   for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) sred[i] = 0.0;
   __syncthreads();
-  const int per = (HW * cg + gridDim.x - 1) / gridDim.x;             // (pixel, channel-group) items per workgroup
-  const int lo = blockIdx.x * per, hi_ = min(lo + per, HW * cg);
-  for (int item = lo + threadIdx.x; item < hi_; item += 256) {
-    const int c8 = item % cg, r = item / cg, y = r / a.W, x = r % a.W;
-    float acc[8];
+  // thread -> fixed channel group c8 and a strided set of this workgroup's pixels, so the
+  // statistics accumulate in registers and reach LDS once per thread
+  const int lanes = 256 / cg;                                         // pixel lanes per workgroup
+  const int c8 = threadIdx.x % cg, pl = threadIdx.x / cg;
+  const int per = (HW + gridDim.x - 1) / gridDim.x;
+  const int p_lo = blockIdx.x * per, p_hi = min(p_lo + per, HW);
+  float wreg[8][9 * 4];                                                // weights of this thread's 8 channels (Cin <= 4)
+  if (pl < lanes)
+    for (int j = 0; j < 8; ++j)
+      for (int k = 0; k < 9 * a.Cin; ++k) wreg[j][k] = a.w[(size_t)(c8 * 8 + j) * a.Cin * 9 + k];
+  double ssum[8], ssq[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = a.bias[c8 * 8 + j];
-    for (int ci = 0; ci < a.Cin; ++ci)
-      for (int dy = 0; dy < 3; ++dy)
-        for (int dx = 0; dx < 3; ++dx) {
-          const int yy = y + dy - 1, xx = x + dx - 1;
-          if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
-          const size_t o = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
+  if (pl < lanes)
+    for (int r = p_lo + pl; r < p_hi; r += lanes) {
+      const int y = r / a.W, x = r % a.W;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = a.bias[c8 * 8 + j];
+      for (int ci = 0; ci < a.Cin; ++ci)
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx) {
+            const int yy = y + dy - 1, xx = x + dx - 1;
+            if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+            const size_t o = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
+            const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
+            const float v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wreg[j][(ci * 3 + dy) * 3 + dx], acc[j]);
+          }
+      if (a.x0_f32 && c8 == 0)
+        for (int ci = 0; ci < a.Cin; ++ci) {
+          const size_t o = (((size_t)b * a.Cin + ci) * a.H + y) * a.W + x;
           const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
-          const float v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, a.w[(((size_t)(c8 * 8 + j) * a.Cin + ci) * 3 + dy) * 3 + dx], acc[j]);
+          a.x0_f32[o] = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
         }
-    if (a.x0_f32 && c8 == 0)
-      for (int ci = 0; ci < a.Cin; ++ci) {
-        const size_t o = (((size_t)b * a.Cin + ci) * a.H + y) * a.W + x;
-        const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
-        a.x0_f32[o] = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
+      const size_t o = ((size_t)b * HW + r) * a.Cout + c8 * 8;
+      if (a.out_f32) {
+        *(float4*)(a.out_f32 + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *(float4*)(a.out_f32 + o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
       }
-    const size_t o = ((size_t)b * HW + r) * a.Cout + c8 * 8;
+      if (a.out_hi)
+        *(uint4*)(a.out_hi + o) = make_uint4(pack2_bf16(acc[0], acc[1]), pack2_bf16(acc[2], acc[3]),
+                                             pack2_bf16(acc[4], acc[5]), pack2_bf16(acc[6], acc[7]));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = acc[j];
-      if (a.out_f32) a.out_f32[o + j] = v;
-      if (a.out_hi) a.out_hi[o + j] = to_bf16(v);
-      if (a.stats) {
-        atomicAdd(&sred[(c8 * 8 + j) * 2], (double)v);
-        atomicAdd(&sred[(c8 * 8 + j) * 2 + 1], (double)v * v);
-      }
+      for (int j = 0; j < 8; ++j) { ssum[j] += acc[j]; ssq[j] += (double)acc[j] * acc[j]; }
     }
-  }
   if (a.stats) {
+    if (pl < lanes)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sred[(c8 * 8 + j) * 2], ssum[j]);
+        atomicAdd(&sred[(c8 * 8 + j) * 2 + 1], ssq[j]);
+      }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) atomicAdd(a.stats + (size_t)b * a.Cout * 2 + i, sred[i]);
   }
@@ -668,7 +685,8 @@ __global__ __launch_bounds__(256) void k_time_mlp(const TimeArgs a) {
     a.act[(size_t)b * a.tdim + o] = s / (1.0f + expf(-s));
   }
 }
-// all ResBlocks' time projections in one launch: out[b][n] = W[n][:] . act[b][:] + bias[n], n < Ntot
+// all ResBlocks' time projections in one launch: out[b][n] = sum_i Wt[i][n] act[b][i] + bias[n], n < Ntot
+// (Wt = the concatenated Linear weights transposed to [tdim][Ntot]: coalesced over n)
 __global__ __launch_bounds__(256) void k_time_proj(const float* __restrict__ act, const float* __restrict__ w,
                                                    const float* __restrict__ bias, int B, int tdim, int Ntot,
                                                    float* __restrict__ out) {
@@ -679,11 +697,7 @@ __global__ __launch_bounds__(256) void k_time_proj(const float* __restrict__ act
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= Ntot) return;
   float s = bias[n];
-  const float* wr = w + (size_t)n * tdim;
-  for (int i = 0; i < tdim; i += 4) {
-    const float4 u = *(const float4*)(wr + i);
-    s = fmaf(u.x, sm[i], s); s = fmaf(u.y, sm[i + 1], s); s = fmaf(u.z, sm[i + 2], s); s = fmaf(u.w, sm[i + 3], s);
-  }
+  for (int i = 0; i < tdim; ++i) s = fmaf(w[(size_t)i * Ntot + n], sm[i], s);     // w is [tdim][Ntot]
   out[(size_t)b * Ntot + n] = s;
 }
 
@@ -846,8 +860,9 @@ extern "C" int ctdd_unet_upsample2x(const void* x, int B, int H, int W, int C, v
 extern "C" int ctdd_unet_first_conv(const void* args_, void* stream) {
   const FirstConvArgs& a = *(const FirstConvArgs*)args_;
   CTDD_REQUIRE((a.x64 || a.x32) && a.w && a.bias && a.Cout % 8 == 0, CTDD_EINVAL, "bad first-conv arguments");
-  const int items = a.H * a.W * (a.Cout / 8);
-  int gx = (items + 1023) / 1024;            // ~4 items per thread: few global atomics, enough workgroups
+  CTDD_REQUIRE(a.Cin <= 4 && a.Cout / 8 <= 256, CTDD_ERANGE, "first conv: Cin=%d Cout=%d", a.Cin, a.Cout);
+  const int lanes = 256 / (a.Cout / 8);
+  int gx = (a.H * a.W + 8 * lanes - 1) / (8 * lanes);     // ~8 pixels per thread
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(k_first_conv, dim3(gx, a.B), dim3(256), (size_t)2 * a.Cout * sizeof(double), (hipStream_t)stream, a);
   return finish_launch("k_first_conv");

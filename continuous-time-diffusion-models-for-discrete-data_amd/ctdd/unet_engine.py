@@ -259,9 +259,9 @@ class UNetEngine:
         # ---- time embedding + all ResBlock projections in two launches
         resblocks = [mod.resblocks for mod in list(net.down) + list(net.mid) + list(net.up) if hasattr(mod, "resblocks")]
         tdim = ch * 4
-        pw = torch.cat([rb.time[1].weight.detach().float() for rb in resblocks], 0).contiguous()
+        pw = torch.cat([rb.time[1].weight.detach().float() for rb in resblocks], 0).t().contiguous()   # [tdim][Ntot]
         pb = torch.cat([rb.time[1].bias.detach().float() for rb in resblocks], 0).contiguous()
-        Ntot = pw.shape[0]
+        Ntot = pw.shape[1]
         st.tact = torch.empty((B, tdim), dtype=torch.float32, device=dev)
         st.tproj = torch.empty((B, Ntot), dtype=torch.float32, device=dev)
         ta = _TimeArgs()

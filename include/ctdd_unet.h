@@ -58,7 +58,8 @@ int ctdd_unet_channel_stats(const float* x, int B, int HW, int C, double* stats,
 typedef struct {
   const float* t; int B, ch, tdim; const float* w1; const float* b1; const float* w2; const float* b2; float* act;
 } ctdd_time_args;
-/* sinusoid -> Linear -> Swish -> Linear -> Swish, then every ResBlock's time projection (unet.py:223-241,332-337,110) */
+/* sinusoid -> Linear -> Swish -> Linear -> Swish, then every ResBlock's time projection (unet.py:223-241,332-337,110);
+ * proj_w = the concatenated projection weights transposed to [tdim][Ntot] */
 int ctdd_unet_time(const void* time_args, const float* proj_w, const float* proj_b, int Ntot, float* proj_out, void* stream);
 
 typedef struct { const float* qkv; int B, T, C, heads; void* out_hi; float* out_f32; } ctdd_attn_args;
