@@ -26,6 +26,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2v = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;   // a 16-byte register quad (a native vector: plain loads, no struct memcpy)
 
 __device__ inline unsigned pack2_bf16(float a, float b) {
   f32x2v v = {a, b};
@@ -67,8 +68,43 @@ constexpr int BM = 128;
 
 // ------------------------------------------------------------------ epilogue shared by the conv kernels
 // One accumulator tile: lane column n, 16 registers = rows wrow0 + (r&3) + 8*(r>>2) + 4*g.
+// GroupNorm statistics of one workgroup tile: the lanes' (sample, column) partial sums meet in LDS
+// (ds_add_f64) and leave as ONE global atomic per (sample, column, moment) and workgroup -- global
+// fp64 atomics execute at the memory side at roughly a wave-instruction per 100+ cycles and CU, and
+// one per lane and accumulator tile was costing more than the matrix work of a K = 864 convolution.
+#ifndef CTDD_EPI_DBG
+#define CTDD_EPI_DBG 0      // scratch ablations of the statistics path
+#endif
+struct TileStats {
+  double* lds;       // [nb][BN][2] or null (no statistics / split-K: k_conv_finish computes them)
+  int b0, nb, n0, BN;
+};
+__host__ __device__ inline int tile_stats_samples(int rows, int HW) { return (rows + HW - 1) / HW + 1; }
+__device__ inline TileStats tile_stats_begin(const ConvArgs& a, unsigned char* smem, int64_t row0, int rows, int n0, int BN,
+                                             int64_t M, int HW) {
+  TileStats ts = {nullptr, 0, 0, n0, BN};
+  if (!a.stats || a.ksplit > 1) return ts;
+  const int64_t rlast = (row0 + rows - 1 < M ? row0 + rows - 1 : M - 1);
+  ts.b0 = (int)((row0 < M ? row0 : M - 1) / HW);
+  ts.nb = (int)(rlast / HW) - ts.b0 + 1;
+  ts.lds = (double*)smem;
+  __syncthreads();                           // the tiles in LDS are out of use
+  for (int i = threadIdx.x; i < ts.nb * BN * 2; i += blockDim.x) ts.lds[i] = 0.0;
+  __syncthreads();
+  return ts;
+}
+__device__ inline void tile_stats_flush(const ConvArgs& a, const TileStats& ts) {
+  if (!ts.lds) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ts.nb * ts.BN * 2; i += blockDim.x) {
+    const int b = ts.b0 + i / (ts.BN * 2), n = ts.n0 + (i >> 1) % ts.BN;
+    const double v = ts.lds[i];
+    if (n < a.N && b < a.B && v != 0.0 && !(CTDD_EPI_DBG & 2)) atomicAdd(a.stats + ((size_t)b * a.N + n) * 2 + (i & 1), v);
+  }
+}
+
 __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, int64_t wrow0, int n, int g,
-                                          int64_t M, int HW) {
+                                          int64_t M, int HW, const TileStats& ts) {
   const bool ncol = n < a.N;
   if (a.ksplit > 1) {                                     // partial sums only; k_conv_finish does the rest
 #pragma unroll
@@ -107,21 +143,143 @@ __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, 
       if (second) { s1 += v; q1 += (double)v * v; } else { s0 += v; q0 += (double)v * v; }
     }
   }
-  if (a.stats) {
+  if (ts.lds) {
     s0 += __shfl_xor(s0, 32, WAVE); q0 += __shfl_xor(q0, 32, WAVE);
     s1 += __shfl_xor(s1, 32, WAVE); q1 += __shfl_xor(q1, 32, WAVE);
-    if (g == 0 && ncol) {
-      double* st = a.stats + ((size_t)b_first * a.N + n) * 2;
+    if (g == 0 && ncol && wrow0 < M) {
+      double* st = ts.lds + ((size_t)(b_first - ts.b0) * ts.BN + (n - ts.n0)) * 2;
       atomicAdd(st, s0);
       atomicAdd(st + 1, q0);
-      if (b_first + 1 < a.B && (s1 != 0.0 || q1 != 0.0)) {
-        atomicAdd(st + (size_t)a.N * 2, s1);
-        atomicAdd(st + (size_t)a.N * 2 + 1, q1);
+      if (b_first + 1 < ts.b0 + ts.nb && (s1 != 0.0 || q1 != 0.0)) {
+        atomicAdd(st + (size_t)ts.BN * 2, s1);
+        atomicAdd(st + (size_t)ts.BN * 2 + 1, q1);
       }
     }
   }
 }
 
+
+// Row-major epilogue of the slab kernels (bf16 mode).  The accumulators of a 32-row slice of the
+// wave's tile go through a wave-private fp32 LDS image and come back as 8-column pieces, one lane
+// per (row, piece): bias / per-sample bias / residual are added with 16-byte loads and the outputs
+// leave as 16-byte stores (the column-per-lane layout of the MFMA result costs one 2-byte store and
+// one 2-byte residual load per element -- measured at half the run time of a K = 864 convolution).
+// Each lane keeps its piece's column sums / sums of squares in fp32 over the <= 8 rows it visits per
+// sample and adds them to the workgroup's fp64 LDS statistics.
+// xt = this wave's [32][32*BNT + 4] fp32 region; rows wrow0 .. wrow0 + 32*MT of the output.
+template <int BNT, int MT>
+__device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)[MT][BNT], float* xt, int64_t wrow0, int n0,
+                                          int64_t M, int HW, const TileStats& ts) {
+  constexpr int BN = 32 * BNT, LD = BN + 4, CH = BN / 8, RS = 64 / CH, STEPS = (32 + RS - 1) / RS;
+  const int lane = threadIdx.x & 63, li = lane & 31, g = lane >> 5;
+  if (a.ksplit > 1) {                                     // partial sums only; k_conv_finish does the rest
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < BNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t p = wrow0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          const int n = n0 + 32 * t + li;
+          if (p < M && n < a.N) atomicAdd(a.acc_buf + (size_t)p * a.N + n, acc[mt][t][r]);
+        }
+    return;
+  }
+  const int cc = lane % CH, rsub = lane / CH;
+  const int nc = n0 + cc * 8;                              // first of this lane's 8 columns
+  const bool lane_ok = rsub < RS && nc < a.N;              // (N is a multiple of 8)
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = (a.bias && lane_ok) ? a.bias[nc + j] : 0.0f;
+  const int S = a.logits_C > 0 ? a.N / a.logits_C : 1;     // logits layout: 8 consecutive n stay inside one channel (S % 8 == 0)
+  const int lch = a.logits_C > 0 ? nc / S : 0, ls = a.logits_C > 0 ? nc % S : 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t base = wrow0 + mt * 32;
+    if (base >= M) break;
+    // ---- phase 1: column-per-lane accumulators -> row-major fp32 image
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xt[((r & 3) + 8 * (r >> 2) + 4 * g) * LD + t * 32 + li] = acc[mt][t][r];
+    // ---- phase 2: one lane per (row, 8-column piece)
+    const int b_first = (int)(base / HW);
+    const int64_t next_sample = (int64_t)(b_first + 1) * HW;   // a 32-row slice spans at most two samples (HW >= 32)
+    float tb0[8], tb1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      tb0[j] = (a.tbias && lane_ok) ? a.tbias[(size_t)b_first * a.tb_stride + nc + j] : 0.0f;
+      tb1[j] = (a.tbias && lane_ok && b_first + 1 < a.B) ? a.tbias[(size_t)(b_first + 1) * a.tb_stride + nc + j] : 0.0f;
+    }
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+      const int row = step * RS + rsub;
+      const int64_t p = base + row;
+      if (lane_ok && row < 32 && p < M) {
+        const bool second = p >= next_sample;
+        const float4 x0 = *(const float4*)(xt + row * LD + cc * 8), x1 = *(const float4*)(xt + row * LD + cc * 8 + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bv[j] + (second ? tb1[j] : tb0[j]);
+        const size_t o = (size_t)p * a.N + nc;
+        if (a.res_bf16) {
+          const uint4 rr = *(const uint4*)(a.res_bf16 + o);
+          const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += __uint_as_float(rw[j] << 16);
+            v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
+          }
+        } else if (a.res_f32) {
+          const float4 r0 = *(const float4*)(a.res_f32 + o), r1 = *(const float4*)(a.res_f32 + o + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        }
+        if (a.out_f32) {
+          float* dst = a.out_f32 + o;
+          if (a.logits_C > 0) {
+            const int b = b_first + (second ? 1 : 0);
+            dst = a.out_f32 + (((size_t)b * a.logits_C + lch) * HW + (p - (int64_t)b * HW)) * S + ls;
+          }
+          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (a.out_hi)
+          *(uint4*)(a.out_hi + o) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+        if (ts.lds) {                                      // final values back into the image for the column pass
+          *(float4*)(xt + row * LD + cc * 8) = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(xt + row * LD + cc * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+    }
+    // ---- phase 3: GroupNorm statistics, one lane per column down the slice's rows (fp64), so that the
+    // LDS atomics are one per (sample, column, moment) and wave slice and hit distinct addresses
+    // (a 64-bit LDS atomic costs ~75 cycles per wave-instruction, more when lanes share an address)
+    if (ts.lds && !(CTDD_EPI_DBG & 1)) {
+      const int nrows = (int)(M - base < 32 ? M - base : 32);
+      const int split = (int)(next_sample - base < nrows ? next_sample - base : nrows);   // rows [0, split) belong to b_first
+#pragma unroll
+      for (int c0 = 0; c0 < BN; c0 += 64) {
+        const int c = c0 + lane;
+        if (c < BN && n0 + c < a.N) {
+          double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+          for (int row = 0; row < split; ++row) { const double x = xt[row * LD + c]; s0 += x; q0 += x * x; }
+          for (int row = split; row < nrows; ++row) { const double x = xt[row * LD + c]; s1 += x; q1 += x * x; }
+          double* st = ts.lds + ((size_t)(b_first - ts.b0) * ts.BN + c) * 2;
+          atomicAdd(st, s0);
+          atomicAdd(st + 1, q0);
+          if (split < nrows) {
+            atomicAdd(st + (size_t)ts.BN * 2, s1);
+            atomicAdd(st + (size_t)ts.BN * 2 + 1, q1);
+          }
+        }
+      }
+    }
+  }
+}
+// bytes of LDS the row-major epilogue needs for NW waves behind the statistics of `rows` output rows
+__host__ __device__ inline size_t epilogue_rows_lds(int nw, int bnt, int rows, int HW) {
+  return (size_t)tile_stats_samples(rows, HW) * 32 * bnt * 16 + (size_t)nw * 32 * (32 * bnt + 4) * 4;
+}
 
 // K-chunk walker: (segment, tap, channel offset), all wave-uniform
 template <int BK>
@@ -284,8 +442,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
   }
 
   // ---- epilogue.  lane: column n = n0 + 32 t + li ; register r: row 32*wave + (r&3) + 8*(r>>2) + 4*g
+  const TileStats ts = tile_stats_begin(a, smem, m0, BM, n0, BN, M, HW);
 #pragma unroll
-  for (int t = 0; t < BNT; ++t) conv_epilogue_tile(a, acc[t], m0 + wave * 32, n0 + 32 * t + li, g, M, HW);
+  for (int t = 0; t < BNT; ++t) conv_epilogue_tile(a, acc[t], m0 + wave * 32, n0 + 32 * t + li, g, M, HW, ts);
+  tile_stats_flush(a, ts);
 }
 
 // ------------------------------------------------------------------ patch convolution (bf16, stride 1)
@@ -448,11 +608,511 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
     u = un; sgi = nsgi; c0 = nc0; kbase = nkbase;
   }
 
+  const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
+  if (!ts.lds) __syncthreads();
+  float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
+  conv_epilogue_rows<BNT, MT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
+  tile_stats_flush(a, ts);
+}
+
+// ------------------------------------------------------------------ resident-weights patch convolution
+// Same slab idea as k_conv_patch, but the weight tiles of ALL taps of a 32-channel chunk are
+// staged together with the slab, so the nine taps run back to back with no barrier and no LDS
+// store between them: per chunk two barriers frame 9 x 2 x MT x BNT matrix instructions per wave.
+// 8 waves x 64 rows = 512 output pixels per workgroup; LDS = slab (<= 46 KB) + 9 x [32*BNT][32]
+// weights (69 KB at BNT = 3), one workgroup per CU with two waves per SIMD.  The next chunk's slab
+// and weights are prefetched into registers under the matrix instructions.
+#ifdef CTDD_RES_STAMPS      // diagnostic build only: per-wave phase durations go to a.acc_buf
+#define RSTAMP(t_) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+#else
+#define RSTAMP(t_)
+#endif
+#ifndef CTDD_RES_DBG
+#define CTDD_RES_DBG 0      // scratch ablations: -1 no matrix work, -2 no restaging, -3 no masks, -4 no LDS reads, -5 reads only
+#endif
+template <int BNT>
+__global__ __launch_bounds__(512) void k_conv_res(const ConvArgs a) {
+  constexpr int BK = 32, WM = 64, MT = 2, NW = 8;
+  constexpr int BN = 32 * BNT, BMP = NW * WM;
+  constexpr int LDK = BK + 8, VPR = BK / 8;
+  constexpr int BVT = BN * VPR;                                  // weight vectors per tap: thread -> (n, cv), 9 taps each
+  static_assert(BVT <= 512, "one weight vector per thread and tap");
+  constexpr int PVMAX = ((BMP + 2 * 34) * VPR + 511) / 512;     // W <= 33
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, g = lane >> 5;
+  const int HW = a.H * a.W, Wd = a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int64_t p0 = (int64_t)blockIdx.x * BMP;
+  const int n0 = blockIdx.y * BN;
+  const int halo = Wd + 1;
+  const int PR = BMP + 2 * halo;
+  unsigned short* Ap = (unsigned short*)smem;                   // [PR][LDK]
+  unsigned short* Bs = Ap + (size_t)PR * LDK;                   // [9][BN][LDK]
+  const int npv = PR * VPR;
+
+  // per-lane validity of (tap, row tile): bit tap*MT + mt
+  unsigned vmask = 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t p = p0 + wave * WM + mt * 32 + li;
+    const bool in = p < M;
+    const int r = (int)((in ? p : 0) % HW);
+    const int oy = r / Wd, ox = r % Wd;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const bool ok = in && (unsigned)(oy + dy - 1) < (unsigned)a.H && (unsigned)(ox + dx - 1) < (unsigned)Wd;
+      vmask |= (ok ? 1u : 0u) << (tap * MT + mt);
+    }
+  }
+
+  int nunits = 0;
+  for (int sgi = 0; sgi < a.nseg; ++sgi) nunits += a.seg[sgi].C / BK;
+  const int zs = blockIdx.z, nz = a.ksplit > 1 ? a.ksplit : 1;
+
+  // staging registers: slab vector i of this thread = slab row tid/4 + 128 i, 16-byte column tid%4;
+  // weights: thread (n = tid/4, cv = tid%4) takes that 16-byte piece of all nine taps.  All the
+  // addresses are one per-thread offset plus wave-uniform terms, recomputed per unit (the opaque
+  // asm keeps the compiler from hoisting a dozen of loop-invariant pointers into registers).
+  u32x4 rp[PVMAX], rb[9];
+  auto unit_info = [&](int u, int& sgi, int& c0, int& kbase) {
+    int k = 0;
+    sgi = 0;
+    while (u >= a.seg[sgi].C / BK) {
+      u -= a.seg[sgi].C / BK;
+      k += a.seg[sgi].C * (a.seg[sgi].kind == SEG_1x1 ? 1 : 9);
+      ++sgi;
+    }
+    c0 = u * BK;
+    kbase = k + c0;
+  };
+  auto load_unit = [&](int sgi, int c0, int kbase) {
+    const ConvSeg sg = a.seg[sgi];
+    const bool one = sg.kind == SEG_1x1;
+    const int hl = one ? 0 : halo;
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int row = tv >> 2, cv = tv & 3;
+    // Every load is unconditional on a clamped address: slab rows outside the tensor (and weight
+    // rows >= N) hold other rows' data, which is harmless -- such slab rows are only read by taps
+    // whose validity bit is clear (the fragment is zeroed), such columns are never written back.
+    // (Predicated loads made the compiler wait for memory in the middle of the issue sequence.)
+    const int64_t q0 = p0 - hl;                                       // wave-uniform first slab pixel
+    const unsigned short* sbase = sg.hi + c0 + cv * 8;
+#pragma unroll
+    for (int i = 0; i < PVMAX; ++i) {
+      int64_t q = q0 + row + 128 * i;
+      q = q < 0 ? 0 : (q >= M ? M - 1 : q);
+      rp[i] = *(const u32x4*)(sbase + (size_t)q * sg.C);
+    }
+    int nrow = n0 + row;
+    nrow = nrow < a.N ? nrow : a.N - 1;
+    const unsigned short* wbase = a.w_hi + (size_t)nrow * a.Ktot + kbase + cv * 8;
+    if (wave * 64 < BVT) {                                            // whole waves: BVT is a multiple of 64
+      rb[0] = *(const u32x4*)wbase;
+      if (!one) {
+#pragma unroll
+        for (int tap = 1; tap < 9; ++tap) rb[tap] = *(const u32x4*)(wbase + (size_t)tap * sg.C);
+      }
+    }
+  };
+  auto store_unit = [&](bool one) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int row = tv >> 2, cv = tv & 3;
+    unsigned short* at = Ap + (size_t)row * LDK + cv * 8;
+#pragma unroll
+    for (int i = 0; i < PVMAX; ++i)
+      if (row + 128 * i < PR) *(u32x4*)(at + (size_t)i * 128 * LDK) = rp[i];
+    unsigned short* bt = Bs + (size_t)row * LDK + cv * 8;
+    if (wave * 64 < BVT) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        if (tap == 0 || !one) *(u32x4*)(bt + (size_t)tap * BN * LDK) = rb[tap];
+    }
+  };
+
+  f32x16 acc[MT][BNT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < BNT; ++t)
-      conv_epilogue_tile(a, acc[mt][t], p0 + wave * WM + mt * 32, n0 + 32 * t + li, g, M, HW);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.0f;
+
+  // (tap, k-step) pipeline: the fragments of step i+1 are read from LDS before the matrix
+  // instructions of step i are issued (two fragment sets in registers); sched_barrier pins that order
+  auto read_frags = [&](const unsigned short* Aw, const unsigned short* Bw, u32x4 (&af)[MT], u32x4 (&bf)[BNT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const u32x4*)(Aw + (size_t)mt * 32 * LDK);
+#pragma unroll
+    for (int t = 0; t < BNT; ++t) bf[t] = *(const u32x4*)(Bw + (size_t)t * 32 * LDK);
+  };
+  auto mfma_step = [&](u32x4 (&af)[MT], const u32x4 (&bf)[BNT], unsigned okbits) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (!((okbits >> mt) & 1u)) af[mt] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bf[t]),
+                                                             acc[mt][t], 0, 0, 0);
+  };
+
+#ifdef CTDD_RES_STAMPS
+  unsigned long long tk0, tk1, tk2, tk3, tk4, tk5, dur[6] = {0, 0, 0, 0, 0, 0}, tstart;
+  RSTAMP(tstart)
+#endif
+  int u = zs;
+  int sgi = 0, c0 = 0, kbase = 0;
+  if (u < nunits) {
+    unit_info(u, sgi, c0, kbase);
+    load_unit(sgi, c0, kbase);
+  }
+  while (u < nunits) {
+    const bool one = a.seg[sgi].kind == SEG_1x1;
+    RSTAMP(tk0)
+    __syncthreads();                       // previous unit's slab and weights are out of use
+    RSTAMP(tk1)
+    if (CTDD_RES_DBG != -2 || u == zs) store_unit(one);
+    RSTAMP(tk2)
+    __syncthreads();
+    RSTAMP(tk3)
+    const int un = u + nz;
+    int nsgi = 0, nc0 = 0, nkbase = 0;
+    if (un < nunits) {
+      unit_info(un, nsgi, nc0, nkbase);
+      if (CTDD_RES_DBG != -2) load_unit(nsgi, nc0, nkbase);
+    }
+    RSTAMP(tk4)
+    // tap loop (runtime trip count: 9, or 1 for a 1x1 segment), two k-steps per tap, software
+    // pipelined over two fragment sets: set 1 (k-step 1) is read before the k-step-0 matrix
+    // instructions issue, the next tap's set 0 before the k-step-1 ones
+    const unsigned short* Bw = Bs + (size_t)li * LDK + g * 8;
+    const unsigned short* A0 = Ap + (size_t)((one ? 0 : halo) + wave * WM + li) * LDK + g * 8;
+    const int ntap = CTDD_RES_DBG == -1 ? 0 : (one ? 1 : 9);
+    u32x4 fa[2][MT], fb[2][BNT];
+    read_frags(A0 + (one ? 0 : (-Wd - 1) * LDK), Bw, fa[0], fb[0]);
+    constexpr int dbg = CTDD_RES_DBG;
+#pragma unroll 1
+    for (int tap = 0; tap < ntap; ++tap) {
+      const int aoff = one ? 0 : ((tap / 3 - 1) * Wd + (tap % 3 - 1)) * LDK;
+      const unsigned okbits = dbg == -3 ? 3u : (vmask >> ((one ? 4 : tap) * MT)) & 3u;
+      if constexpr (dbg != -4) read_frags(A0 + aoff + 16, Bw + (size_t)tap * BN * LDK + 16, fa[1], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (dbg != -5) mfma_step(fa[0], fb[0], okbits);
+      __builtin_amdgcn_sched_barrier(0);
+      const int tn = tap + 1 < ntap ? tap + 1 : tap;              // (the last tap re-reads itself: no branch)
+      const int noff = one ? 0 : ((tn / 3 - 1) * Wd + (tn % 3 - 1)) * LDK;
+      if constexpr (dbg != -4) read_frags(A0 + noff, Bw + (size_t)tn * BN * LDK, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (dbg != -5) mfma_step(fa[1], fb[1], okbits);
+      else { acc[0][0][0] += __uint_as_float(fa[0][0][0] ^ fa[1][1][1] ^ fb[0][0][0] ^ fb[1][BNT - 1][3] ^ fb[0][1][0] ^ fb[1][0][2] ^ fa[0][1][0] ^ fa[1][0][0]); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    RSTAMP(tk5)
+#ifdef CTDD_RES_STAMPS
+    dur[0] += tk1 - tk0; dur[1] += tk2 - tk1; dur[2] += tk3 - tk2; dur[3] += tk4 - tk3; dur[4] += tk5 - tk4;
+#endif
+    u = un; sgi = nsgi; c0 = nc0; kbase = nkbase;
+  }
+#ifdef CTDD_RES_STAMPS
+  {
+    unsigned long long tend;
+    RSTAMP(tend)
+    if (lane == 0 && a.acc_buf) {
+      unsigned long long* o = (unsigned long long*)a.acc_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+      for (int i = 0; i < 5; ++i) o[i] = dur[i];
+      o[5] = tstart; o[6] = tend; o[7] = tend - tstart;
+    }
+  }
+#endif
+
+  const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
+  if (!ts.lds) __syncthreads();
+  float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
+  conv_epilogue_rows<BNT, MT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
+  tile_stats_flush(a, ts);
+}
+
+// ------------------------------------------------------------------ ring convolution (LDS-DMA, no staging registers)
+// The slab idea of k_conv_patch with the staging taken off the waves: per 16-channel unit the
+// slab (19 pieces of 32 rows x 32 B) and the weights of all nine taps (9*BNT pieces) are moved
+// global -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction) into a ring of NBUF unit
+// buffers, one or two units ahead of the matrix instructions.  No staging registers, no ds_write,
+// ONE barrier per unit; the DMA of a later unit is issued piece by piece between the taps of the
+// current one.  LDS rows are 32 B (unpadded, as the DMA writes them); the two 16-B halves of row r
+// are swapped when bit 3 of r is set, which makes every ds_read_b128 lane group hit 16 distinct
+// bank quads for any tap offset.  8 waves x 64 rows = 512 output pixels per workgroup, 32*BNT
+// output channels.
+//
+// The matrix pipe shares each wave's issue slots with everything else the wave executes (one
+// instruction per wave every four cycles, a 32x32x16 MFMA occupying the pipe for 32), so the tap
+// body is kept to ~30 instructions per six MFMAs: the nine taps of a 3x3 unit are unrolled (tap
+// offsets, fragment registers and validity bits become constants), per-lane addresses are
+// computed once per kernel, and a DMA op is one vector instruction on a scalar base.  Units of
+// 1x1 segments run in a second, rolled loop after all 3x3 units (two loops instead of one
+// branchy body keep the accumulators in place).
+template <int BNT, int NBUF>
+__global__ __launch_bounds__(512) void k_conv_ring(const ConvArgs a) {
+  constexpr int BK = 16, WM = 64, MT = 2, NW = 8;
+  constexpr int BN = 32 * BNT, BMP = NW * WM;
+  constexpr int SP = 19;                                         // slab pieces: 608 rows >= 512 + 2*(33+1)
+  constexpr int SLABB = SP * 1024, BUFB = SLABB + 9 * BN * 32;
+  constexpr int OPS3 = (SP + 9 * BNT + NW - 1) / NW;             // DMA ops per wave for a 3x3 unit
+  constexpr int OPS1 = (16 + BNT + NW - 1) / NW;                 // ... for a 1x1 unit (512 rows, one tap)
+  constexpr int DEPTH = NBUF - 1;                                // units in flight ahead of the one computed
+  static_assert(DEPTH == 1 || DEPTH == 2, "ring of two or three unit buffers");
+  static_assert(OPS3 <= 9, "one DMA op per tap");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, g = lane >> 5;
+  const int HW = a.H * a.W, Wd = a.W;
+  const int64_t M = (int64_t)a.B * HW;
+  const int64_t p0 = (int64_t)blockIdx.x * BMP;
+  const int n0 = blockIdx.y * BN;
+  const int halo = Wd + 1;
+  const int Ntot = a.N, Ktot = a.Ktot;
+
+  // per-lane validity of (tap, row tile): bit tap*MT + mt
+  unsigned vmask = 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t p = p0 + wave * WM + mt * 32 + li;
+    const bool in = p < M;
+    const int r = (int)((in ? p : 0) % HW);
+    const int oy = r / Wd, ox = r % Wd;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const bool ok = in && (unsigned)(oy + dy - 1) < (unsigned)a.H && (unsigned)(ox + dx - 1) < (unsigned)Wd;
+      vmask |= (ok ? 1u : 0u) << (tap * MT + mt);
+    }
+  }
+
+  // ---- unit order of this z-slice: all 16-channel units of 3x3 segments, then those of 1x1 segments
+  int n33 = 0, n11 = 0;
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    if (a.seg[sgi].kind == SEG_1x1) n11 += a.seg[sgi].C / BK;
+    else n33 += a.seg[sgi].C / BK;
+  }
+  const int nunits = n33 + n11;
+  const int zs = blockIdx.z, nz = a.ksplit > 1 ? a.ksplit : 1;
+  const int myunits = zs < nunits ? (nunits - zs + nz - 1) / nz : 0;     // sorted units zs, zs+nz, ...
+
+  // Everything a DMA op needs from the segment table, fetched once per unit (scalar loads inside
+  // the tap loop would make every tap wait for lgkmcnt(0), i.e. for its own prefetched fragments).
+  struct Unit { const unsigned char* src; const unsigned char* wsrc; int C; bool one; };
+  auto unit_info = [&](int su) {                                 // su = index in the sorted order
+    const bool one = su >= n33;
+    int u = one ? su - n33 : su;
+    Unit r = {nullptr, nullptr, 16, one};
+    int k = 0;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) {
+      const bool sone = a.seg[sgi].kind == SEG_1x1;
+      const int nu = a.seg[sgi].C / BK;
+      if (sone == one && u >= 0 && u < nu) {
+        r.C = a.seg[sgi].C;
+        r.src = (const unsigned char*)(a.seg[sgi].hi + u * BK);          // channel chunk of the segment's tensor
+        r.wsrc = (const unsigned char*)(a.w_hi + k + u * BK);            // its K offset in a weight row (tap 0)
+        u = -1;
+      } else if (sone == one && u >= 0) {
+        u -= nu;
+      }
+      k += a.seg[sgi].C * (sone ? 1 : 9);
+    }
+    return r;
+  };
+
+  // DMA op j of this wave for unit `un` into ring buffer `buf`: piece = wave + 8 j (clamped: the
+  // last pieces may be issued twice, same bytes to the same place).  Lane l fills LDS bytes
+  // [16 l, 16 l + 16) of the piece = row l/2, stored half l&1.  Addresses are a wave-uniform 64-bit
+  // base plus one 32-bit per-lane offset.  Slab rows outside the tensor read clamped addresses:
+  // they are only consumed under a cleared validity bit.  Column tiles that would start beyond N
+  // re-read the last 32 weight rows: never written back.
+  const int rl = lane >> 1;
+  const unsigned swz16 = (unsigned)(((lane & 1) ^ ((rl >> 3) & 1)) << 4);   // byte offset of the lane's half
+  const unsigned wlane = (unsigned)rl * (unsigned)Ktot * 2u + swz16;
+  auto issue_op = [&](const Unit& un, unsigned slane, int buf, int j) {      // slane = rl * C * 2 + swz16 for un.C
+    const int nsp = un.one ? 16 : SP;
+    const int total = nsp + (un.one ? BNT : 9 * BNT);
+    int p = wave + NW * j;
+    p = p < total ? p : total - 1;
+    const unsigned char* src;
+    unsigned char* dst = smem + (size_t)buf * BUFB;
+    if (p < nsp) {
+      const int64_t q0 = p0 - (un.one ? 0 : halo) + p * 32;               // wave-uniform first pixel of the piece
+      if (q0 >= 0 && q0 + 32 <= M) {
+        src = un.src + (size_t)q0 * un.C * 2 + slane;
+      } else {
+        int64_t q = q0 + rl;
+        q = q < 0 ? 0 : (q >= M ? M - 1 : q);
+        src = un.src + (size_t)q * un.C * 2 + swz16;
+      }
+      dst += (size_t)p * 1024;
+    } else {
+      const int wp = p - nsp;                                    // = tap * BNT + t
+      const int tap = wp / BNT;
+      int nb = n0 + (wp - tap * BNT) * 32;
+      nb = nb + 32 <= Ntot ? nb : Ntot - 32;
+      src = un.wsrc + ((size_t)nb * Ktot + (size_t)tap * un.C) * 2 + wlane;
+      dst += SLABB + (size_t)wp * 1024;
+    }
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
+  };
+  auto slane_of = [&](const Unit& un) { return (unsigned)rl * (unsigned)un.C * 2u + swz16; };
+
+  f32x16 acc[MT][BNT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.0f;
+
+  // Fragment reads issue B first and A last, and the A fragments are the first thing a tap touches
+  // (mask_a): the wait for them covers the whole set and sits BEFORE the next set's reads issue.
+  // (An LDS-DMA op makes the compiler's next LDS wait an lgkmcnt(0); in this order that is the
+  // count the tap needs anyway, so nothing in flight is drained early.)
+  auto read_frags = [&](unsigned aoff, unsigned boff, u32x4 (&af)[MT], u32x4 (&bf)[BNT]) {
+#pragma unroll
+    for (int t = 0; t < BNT; ++t) bf[t] = *(const u32x4*)(smem + boff + t * 1024);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = *(const u32x4*)(smem + aoff + mt * 1024);
+  };
+  auto mask_a = [&](u32x4 (&af)[MT], int bit0) {                 // validity bits bit0 + mt of vmask
+#pragma unroll
+    for (int mt = MT - 1; mt >= 0; --mt) {
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe(vmask, bit0 + mt, 1);   // 0 or ~0
+      af[mt] &= m;
+    }
+  };
+  auto mfma_step = [&](const u32x4 (&af)[MT], const u32x4 (&bf)[BNT]) {
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bf[t]),
+                                                             acc[mt][t], 0, 0, 0);
+  };
+
+  // slab byte offset (swizzled) of this lane's A fragment under every tap, row tile 0 (x + 32 has the
+  // same bit 3: row tile 1 = +1024 B); 1x1 units have no halo rows
+  unsigned aoff[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int x = halo + wave * WM + li + (tap / 3 - 1) * Wd + (tap % 3 - 1);
+    aoff[tap] = (unsigned)(x * 32 + ((g ^ ((x >> 3) & 1)) << 4));
+  }
+  const unsigned aoff1 = (unsigned)((wave * WM + li) * 32 + ((g ^ ((li >> 3) & 1)) << 4));   // (wave*64 + li: bit 3 = bit 3 of li)
+  const unsigned boff = (unsigned)(SLABB + li * 32 + ((g ^ ((li >> 3) & 1)) << 4));          // weight rows: bit 3 of the row = bit 3 of li
+
+#ifdef CTDD_RES_STAMPS
+  unsigned long long tk0, tk1, tk2, tk3, tk4, dur[6] = {0, 0, 0, 0, 0, 0}, tstart;
+  RSTAMP(tstart)
+#endif
+  // ---- prologue: the first DEPTH units of this z-slice, all ops at once
+  Unit cur = {nullptr, nullptr, 16, false}, nx1 = cur, nxt = cur;        // units k, k+1 (DEPTH 2), k+DEPTH
+  if (myunits > 0) {
+    cur = unit_info(zs);
+    const unsigned sl = slane_of(cur);
+    for (int j = 0; j < (cur.one ? OPS1 : OPS3); ++j) issue_op(cur, sl, 0, j);
+  }
+  if (DEPTH == 2 && myunits > 1) {
+    nx1 = unit_info(zs + nz);
+    const unsigned sl = slane_of(nx1);
+    for (int j = 0; j < (nx1.one ? OPS1 : OPS3); ++j) issue_op(nx1, sl, 1, j);
+  }
+
+  int buf = 0, k = 0;
+  // top of a unit: wait for its pieces, barrier, pick the unit to fetch meanwhile
+  int nbuf = 0, nops = 0;
+  unsigned nsl = 0;
+  auto unit_top = [&]() {
+    RSTAMP(tk0)
+    // unit k has landed once at most the ops of the younger unit in flight remain
+    if (DEPTH == 2 && k + 1 < myunits) {
+      if (nx1.one) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS3) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RSTAMP(tk1)
+    __builtin_amdgcn_s_barrier();          // everyone's pieces of unit k are in LDS; unit k-1's buffer is out of use
+    RSTAMP(tk2)
+    const int kn = k + DEPTH;              // the unit to start fetching now, into the buffer unit k-1 used
+    nbuf = buf == 0 ? NBUF - 1 : buf - 1;
+    nops = 0;
+    if (kn < myunits) {
+      nxt = unit_info(zs + kn * nz);
+      nops = nxt.one ? OPS1 : OPS3;
+      nsl = slane_of(nxt);
+    }
+    RSTAMP(tk4)
+  };
+  auto unit_bottom = [&]() {
+    RSTAMP(tk3)
+#ifdef CTDD_RES_STAMPS
+    dur[0] += tk1 - tk0; dur[1] += tk2 - tk1; dur[3] += tk4 - tk2; dur[4] += tk3 - tk4;
+#endif
+    if (DEPTH == 2) { cur = nx1; nx1 = nxt; } else { cur = nxt; }
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    ++k;
+  };
+
+  // ---- 3x3 units: nine unrolled taps, two fragment sets alternating
+  const int my33 = zs < n33 ? (n33 - zs + nz - 1) / nz : 0;              // how many of my units are 3x3
+  for (; k < my33;) {
+    unit_top();
+    const unsigned sb = (unsigned)buf * BUFB;
+    u32x4 fa[2][MT], fb[2][BNT];
+    read_frags(sb + aoff[0], sb + boff, fa[0], fb[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // wait + mask this tap's A | read the next tap's set | one DMA op | matrix instructions
+      mask_a(fa[tap & 1], tap * MT);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 9) read_frags(sb + aoff[tap + 1], sb + boff + (tap + 1) * BN * 32, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+      if (tap < OPS3 && tap < nops) issue_op(nxt, nsl, nbuf, tap);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(fa[tap & 1], fb[tap & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    unit_bottom();
+  }
+  // ---- 1x1 units: one tap each (centre-tap validity)
+  for (; k < myunits;) {
+    unit_top();
+    const unsigned sb = (unsigned)buf * BUFB;
+    u32x4 fa[MT], fb[BNT];
+    read_frags(sb + aoff1, sb + boff, fa, fb);
+    for (int j = 0; j < nops; ++j) issue_op(nxt, nsl, nbuf, j);
+    mask_a(fa, 4 * MT);
+    mfma_step(fa, fb);
+    unit_bottom();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CTDD_RES_STAMPS
+  {
+    unsigned long long tend;
+    RSTAMP(tend)
+    if (lane == 0 && a.acc_buf) {
+      unsigned long long* o = (unsigned long long*)a.acc_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+      for (int i = 0; i < 5; ++i) o[i] = dur[i];
+      o[5] = tstart; o[6] = tend; o[7] = tend - tstart;
+    }
+  }
+#endif
+
+  const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
+  if (!ts.lds) __syncthreads();
+  float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
+  conv_epilogue_rows<BNT, MT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
+  tile_stats_flush(a, ts);
 }
 
 // split-K finish: acc_buf (+ bias, time bias, residual) -> outputs and GroupNorm statistics
@@ -509,6 +1169,7 @@ struct FirstConvArgs {
   float* out_f32; unsigned short* out_hi; double* stats;
   float* x0_f32;              // optional centred input (B,Cin,H,W) fp32 (logistic head needs it)
 };
+template <int CIN>
 __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sred[];     // [Cout][2] per-workgroup partial statistics
   const int cg = a.Cout / 8, HW = a.H * a.W, b = blockIdx.y;
@@ -520,10 +1181,10 @@ __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
   const int c8 = threadIdx.x % cg, pl = threadIdx.x / cg;
   const int per = (HW + gridDim.x - 1) / gridDim.x;
   const int p_lo = blockIdx.x * per, p_hi = min(p_lo + per, HW);
-  float wreg[8][9 * 4];                                                // weights of this thread's 8 channels (Cin <= 4)
+  float wreg[8][9 * CIN];                                              // weights of this thread's 8 channels
   if (pl < lanes)
     for (int j = 0; j < 8; ++j)
-      for (int k = 0; k < 9 * a.Cin; ++k) wreg[j][k] = a.w[(size_t)(c8 * 8 + j) * a.Cin * 9 + k];
+      for (int k = 0; k < 9 * CIN; ++k) wreg[j][k] = a.w[(size_t)(c8 * 8 + j) * CIN * 9 + k];
   double ssum[8], ssq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
@@ -533,20 +1194,23 @@ __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = a.bias[c8 * 8 + j];
-      for (int ci = 0; ci < a.Cin; ++ci)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
         for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
             const int yy = y + dy - 1, xx = x + dx - 1;
             if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
-            const size_t o = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
+            const size_t o = (((size_t)b * CIN + ci) * a.H + yy) * a.W + xx;
             const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
             const float v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wreg[j][(ci * 3 + dy) * 3 + dx], acc[j]);
           }
       if (a.x0_f32 && c8 == 0)
-        for (int ci = 0; ci < a.Cin; ++ci) {
-          const size_t o = (((size_t)b * a.Cin + ci) * a.H + y) * a.W + x;
+        for (int ci = 0; ci < CIN; ++ci) {
+          const size_t o = (((size_t)b * CIN + ci) * a.H + y) * a.W + x;
           const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
           a.x0_f32[o] = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
         }
@@ -658,47 +1322,62 @@ __global__ __launch_bounds__(256) void k_channel_stats(const float* __restrict__
 // temb = W2 swish(W1 [sin(t f) | cos(t f)] + b1) + b2 ; out = swish(temb)  (every ResBlock projects swish(temb))
 struct TimeArgs {
   const float* t; int B, ch, tdim;
-  const float* w1; const float* b1; const float* w2; const float* b2;   // torch Linear layouts [out][in]
+  const float* w1; const float* b1; const float* w2; const float* b2;   // Linear weights transposed to [in][out]
+  float* hid;   // [B][tdim] scratch = swish(W1 e + b1)
   float* act;   // [B][tdim] = swish(temb)
 };
-__global__ __launch_bounds__(256) void k_time_mlp(const TimeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* e = sm;               // [ch]
-  float* h = sm + a.ch;        // [tdim]
-  const int b = blockIdx.x, half = a.ch / 2;
-  const float t = a.t[b];
-  for (int i = threadIdx.x; i < half; i += 256) {
-    const float f = expf((float)i * (-logf(10000.0f) / (float)(half - 1)));
-    e[i] = sinf(t * f);
-    e[half + i] = cosf(t * f);
+// One row-blocked linear layer serves the three steps (sinusoid -> W1 -> swish, W2 -> swish, all the
+// ResBlock projections): out[b][n] = f(bias[n] + sum_i wt[i][n] x[b][i]), wt = [K][N] (coalesced over
+// n).  A workgroup = 64 columns x 16 batch rows; its four waves take a quarter of K each (every weight
+// is streamed once per 16 rows; one row per workgroup re-read the whole matrix from L2 per row, 1.5 GB
+// per forward at batch 256) and the four partial sums are added in wave order.
+constexpr int TRB = 16;
+template <bool SINUSOID, bool SWISH>
+__global__ __launch_bounds__(256) void k_rows_linear(const float* __restrict__ x, const float* __restrict__ wt,
+                                                     const float* __restrict__ bias, int B, int K, int N,
+                                                     float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [TRB][K] inputs, then [4][TRB][64] partial sums
+  const int b0 = blockIdx.y * TRB;
+  for (int i = threadIdx.x; i < TRB * K; i += 256) {
+    const int r = i / K, c = i % K, b = b0 + r < B ? b0 + r : B - 1;
+    if (SINUSOID) {                                            // x = t[B]; embedding [sin(t f) | cos(t f)], f_j = 10000^(-j/(half-1))
+      const int half = K / 2, j = c < half ? c : c - half;
+      const float f = expf((float)j * (-logf(10000.0f) / (float)(half - 1)));
+      sm[i] = c < half ? sinf(x[b] * f) : cosf(x[b] * f);
+    } else {
+      sm[i] = x[(size_t)b * K + c];
+    }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < a.tdim; o += 256) {
-    float s = a.b1[o];
-    for (int i = 0; i < a.ch; ++i) s = fmaf(a.w1[(size_t)o * a.ch + i], e[i], s);
-    h[o] = s / (1.0f + expf(-s));
+  const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + col, nc = n < N ? n : N - 1;
+  const int kq = K / 4, k0 = ks * kq;                          // K % 16 == 0
+  float acc[TRB];
+#pragma unroll
+  for (int r = 0; r < TRB; ++r) acc[r] = 0.0f;
+#pragma unroll 2
+  for (int i = k0; i < k0 + kq; i += 4) {
+    const float w0 = wt[(size_t)i * N + nc], w1 = wt[(size_t)(i + 1) * N + nc], w2 = wt[(size_t)(i + 2) * N + nc],
+                w3 = wt[(size_t)(i + 3) * N + nc];
+#pragma unroll
+    for (int r = 0; r < TRB; ++r) {
+      const float4 xv = *(const float4*)(sm + r * K + i);
+      acc[r] = fmaf(w3, xv.w, fmaf(w2, xv.z, fmaf(w1, xv.y, fmaf(w0, xv.x, acc[r]))));
+    }
   }
+  __syncthreads();                                             // inputs are out of use: reuse the LDS for the partial sums
+  float* part = sm;
+#pragma unroll
+  for (int r = 0; r < TRB; ++r) part[(ks * TRB + r) * 64 + col] = acc[r];
   __syncthreads();
-  for (int o = threadIdx.x; o < a.tdim; o += 256) {
-    float s = a.b2[o];
-    for (int i = 0; i < a.tdim; ++i) s = fmaf(a.w2[(size_t)o * a.tdim + i], h[i], s);
-    a.act[(size_t)b * a.tdim + o] = s / (1.0f + expf(-s));
+  for (int i = threadIdx.x; i < TRB * 64; i += 256) {
+    const int r = i >> 6, c = i & 63, nn = blockIdx.x * 64 + c;
+    if (nn < N && b0 + r < B) {
+      const float v = (((bias[nn] + part[(0 * TRB + r) * 64 + c]) + part[(1 * TRB + r) * 64 + c]) + part[(2 * TRB + r) * 64 + c]) +
+                      part[(3 * TRB + r) * 64 + c];
+      out[(size_t)(b0 + r) * N + nn] = SWISH ? v / (1.0f + expf(-v)) : v;
+    }
   }
-}
-// all ResBlocks' time projections in one launch: out[b][n] = sum_i Wt[i][n] act[b][i] + bias[n], n < Ntot
-// (Wt = the concatenated Linear weights transposed to [tdim][Ntot]: coalesced over n)
-__global__ __launch_bounds__(256) void k_time_proj(const float* __restrict__ act, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, int B, int tdim, int Ntot,
-                                                   float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // act[b][:]
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < tdim; i += 256) sm[i] = act[(size_t)b * tdim + i];
-  __syncthreads();
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= Ntot) return;
-  float s = bias[n];
-  for (int i = 0; i < tdim; ++i) s = fmaf(w[(size_t)i * Ntot + n], sm[i], s);     // w is [tdim][Ntot]
-  out[(size_t)b * Ntot + n] = s;
 }
 
 // ------------------------------------------------------------------ mid-block self-attention (unet.py:152-200)
@@ -777,7 +1456,9 @@ template <int BK, int BNT, bool F32>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int ESZ = F32 ? 4 : 2;
   constexpr int LDK = BK + 16 / ESZ;
-  const size_t lds = (size_t)(BM + 32 * BNT) * LDK * ESZ;
+  size_t lds = (size_t)(BM + 32 * BNT) * LDK * ESZ;
+  const size_t stats_lds = (size_t)tile_stats_samples(BM, a.H * a.W) * 32 * BNT * 16;
+  if (lds < stats_lds) lds = stats_lds;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   dim3 g((unsigned)((M + BM - 1) / BM), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)));
   static bool attr_done = false;            // once per instantiation (not legal inside stream capture)
@@ -811,7 +1492,9 @@ template <int BK, int BNT, int WM>
 static int launch_patch(const ConvArgs& a, hipStream_t st) {
   constexpr int LDK = BK + 8;
   const int PR = 4 * WM + 2 * (a.W + 1);
-  const size_t lds = ((size_t)PR + 2 * 32 * BNT) * LDK * 2;
+  size_t lds = ((size_t)PR + 2 * 32 * BNT) * LDK * 2;
+  const size_t epi_lds = epilogue_rows_lds(4, BNT, 4 * WM, a.H * a.W);
+  if (lds < epi_lds) lds = epi_lds;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   dim3 g((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), a.ksplit > 1 ? a.ksplit : 1);
   static bool attr_done = false;
@@ -833,6 +1516,9 @@ extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, 
   CTDD_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.w_hi, CTDD_EINVAL, "bad conv arguments");
   CTDD_REQUIRE(a.W <= 33, CTDD_ERANGE, "W=%d > 33", a.W);
   CTDD_REQUIRE(a.Hin == a.H && a.Win == a.W, CTDD_EINVAL, "patch conv is stride 1");
+  CTDD_REQUIRE(a.N % 8 == 0 && ((int64_t)a.H * a.W >= 32 || a.H * a.W == 16 || a.B == 1), CTDD_ERANGE,
+               "patch conv: N=%d H*W=%d (a 32-row slice may span two samples at most)", a.N, a.H * a.W);
+  CTDD_REQUIRE(a.logits_C <= 0 || (a.N % a.logits_C == 0 && (a.N / a.logits_C) % 8 == 0), CTDD_EINVAL, "logits layout needs S %% 8 == 0");
   for (int i = 0; i < a.nseg; ++i) {
     CTDD_REQUIRE(a.seg[i].hi && a.seg[i].C % bk == 0, CTDD_EINVAL, "segment %d: C=%d vs BK=%d", i, a.seg[i].C, bk);
     CTDD_REQUIRE(a.seg[i].kind == SEG_3x3 || a.seg[i].kind == SEG_1x1, CTDD_EINVAL, "segment %d: kind %d", i, a.seg[i].kind);
@@ -845,6 +1531,103 @@ extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, 
   CASEP(16, 1, 32)
 #undef CASEP
   CTDD_REQUIRE(false, CTDD_ERANGE, "no patch-conv instantiation for BK=%d BNT=%d WM=%d", bk, bnt, wm);
+}
+
+template <int BNT>
+static int launch_res(const ConvArgs& a, hipStream_t st) {
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  const int nz = a.ksplit > 1 ? a.ksplit : 1;
+  dim3 g((unsigned)((M + 511) / 512), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), (unsigned)nz);
+  size_t lds = ((size_t)(512 + 2 * (a.W + 1)) + (size_t)9 * 32 * BNT) * 40 * 2;
+  const size_t epi_lds = epilogue_rows_lds(8, BNT, 512, a.H * a.W);
+  if (lds < epi_lds) lds = epi_lds;
+  CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "resident conv: %zu bytes of LDS", lds);
+  static bool attr_done = false;               // not inside a stream capture: set once per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_conv_res<BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv_res<BNT>), g, dim3(512), lds, st, a);
+  if (int rc = finish_launch("k_conv_res")) return rc;
+  if (nz > 1) {
+    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
+    return finish_launch("k_conv_finish");
+  }
+  return CTDD_OK;
+}
+
+extern "C" int ctdd_unet_conv_res(const void* args_, int bnt, void* stream) {
+  CTDD_REQUIRE(args_ != nullptr, CTDD_EINVAL, "null args");
+  const ConvArgs& a = *(const ConvArgs*)args_;
+  CTDD_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.w_hi && a.W <= 33, CTDD_EINVAL, "resident conv: nseg=%d W=%d", a.nseg, a.W);
+  CTDD_REQUIRE(a.H == a.Hin && a.W == a.Win, CTDD_EINVAL, "resident conv needs stride 1");
+  CTDD_REQUIRE(a.N % 8 == 0, CTDD_ERANGE, "resident conv: N=%d", a.N);
+  CTDD_REQUIRE(a.logits_C <= 0 || (a.N % a.logits_C == 0 && (a.N / a.logits_C) % 8 == 0), CTDD_EINVAL, "logits layout needs S %% 8 == 0");
+  CTDD_REQUIRE((int64_t)a.H * a.W >= 32 || a.H * a.W == 16 || a.B == 1, CTDD_ERANGE, "resident conv needs H*W >= 32 (or 16)");
+  int k = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    CTDD_REQUIRE(a.seg[i].hi && (a.seg[i].kind == SEG_3x3 || a.seg[i].kind == SEG_1x1) && a.seg[i].C % 32 == 0, CTDD_EINVAL,
+                 "resident conv segment %d: kind=%d C=%d", i, a.seg[i].kind, a.seg[i].C);
+    k += a.seg[i].C * (a.seg[i].kind == SEG_1x1 ? 1 : 9);
+  }
+  CTDD_REQUIRE(k == a.Ktot, CTDD_EINVAL, "Ktot=%d but segments sum to %d", a.Ktot, k);
+  CTDD_REQUIRE(a.ksplit <= 1 || (a.acc_buf && a.logits_C == 0), CTDD_EINVAL, "split-K needs acc_buf");
+  hipStream_t st = (hipStream_t)stream;
+  switch (bnt) {
+    case 2: return launch_res<2>(a, st);
+    case 3: return launch_res<3>(a, st);
+    case 4: return launch_res<4>(a, st);
+  }
+  CTDD_REQUIRE(false, CTDD_ERANGE, "unsupported resident conv tile bnt=%d", bnt);
+}
+
+template <int BNT, int NBUF>
+static int launch_ring(const ConvArgs& a, hipStream_t st) {
+  const int64_t M = (int64_t)a.B * a.H * a.W;
+  const int nz = a.ksplit > 1 ? a.ksplit : 1;
+  dim3 g((unsigned)((M + 511) / 512), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), (unsigned)nz);
+  size_t lds = (size_t)NBUF * (19 * 1024 + 9 * 32 * BNT * 32);
+  const size_t epi_lds = epilogue_rows_lds(8, BNT, 512, a.H * a.W);
+  if (lds < epi_lds) lds = epi_lds;
+  CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "ring conv: %zu bytes of LDS", lds);
+  static bool attr_done = false;               // not inside a stream capture: set once per instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k_conv_ring<BNT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_conv_ring<BNT, NBUF>), g, dim3(512), lds, st, a);
+  if (int rc = finish_launch("k_conv_ring")) return rc;
+  if (nz > 1) {
+    hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
+    return finish_launch("k_conv_finish");
+  }
+  return CTDD_OK;
+}
+
+extern "C" int ctdd_unet_conv_ring(const void* args_, int bnt, void* stream) {
+  CTDD_REQUIRE(args_ != nullptr, CTDD_EINVAL, "null args");
+  const ConvArgs& a = *(const ConvArgs*)args_;
+  CTDD_REQUIRE(a.nseg >= 1 && a.nseg <= 3 && a.w_hi && a.W <= 33, CTDD_EINVAL, "ring conv: nseg=%d W=%d", a.nseg, a.W);
+  CTDD_REQUIRE(a.H == a.Hin && a.W == a.Win, CTDD_EINVAL, "ring conv needs stride 1");
+  CTDD_REQUIRE(a.logits_C <= 0 || (a.N % a.logits_C == 0 && (a.N / a.logits_C) % 8 == 0), CTDD_EINVAL, "logits layout needs S %% 8 == 0");
+  CTDD_REQUIRE((int64_t)a.H * a.W >= 32 || a.H * a.W == 16 || a.B == 1, CTDD_ERANGE, "ring conv needs H*W >= 32 (or 16)");
+  int k = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    CTDD_REQUIRE(a.seg[i].hi && (a.seg[i].kind == SEG_3x3 || a.seg[i].kind == SEG_1x1) && a.seg[i].C % 16 == 0, CTDD_EINVAL,
+                 "ring conv segment %d: kind=%d C=%d", i, a.seg[i].kind, a.seg[i].C);
+    k += a.seg[i].C * (a.seg[i].kind == SEG_1x1 ? 1 : 9);
+  }
+  CTDD_REQUIRE(k == a.Ktot, CTDD_EINVAL, "Ktot=%d but segments sum to %d", a.Ktot, k);
+  CTDD_REQUIRE(a.Ktot % 8 == 0 && a.N % 32 == 0 && a.N >= 32, CTDD_EINVAL, "ring conv: Ktot=%d N=%d (need Ktot %% 8 == 0, N %% 32 == 0)", a.Ktot, a.N);
+  CTDD_REQUIRE((int64_t)a.Ktot * 64 < (int64_t)1 << 31, CTDD_ERANGE, "ring conv: Ktot=%d too large for 32-bit lane offsets", a.Ktot);
+  CTDD_REQUIRE(a.ksplit <= 1 || (a.acc_buf && a.logits_C == 0), CTDD_EINVAL, "split-K needs acc_buf");
+  hipStream_t st = (hipStream_t)stream;
+  switch (bnt) {
+    case 2: return launch_ring<2, 3>(a, st);
+    case 3: return launch_ring<3, 3>(a, st);
+    case 4: return launch_ring<4, 2>(a, st);
+  }
+  CTDD_REQUIRE(false, CTDD_ERANGE, "unsupported ring conv tile bnt=%d", bnt);
 }
 
 extern "C" int ctdd_unet_upsample2x(const void* x, int B, int H, int W, int C, void* out, void* stream) {
@@ -860,11 +1643,18 @@ extern "C" int ctdd_unet_upsample2x(const void* x, int B, int H, int W, int C, v
 extern "C" int ctdd_unet_first_conv(const void* args_, void* stream) {
   const FirstConvArgs& a = *(const FirstConvArgs*)args_;
   CTDD_REQUIRE((a.x64 || a.x32) && a.w && a.bias && a.Cout % 8 == 0, CTDD_EINVAL, "bad first-conv arguments");
-  CTDD_REQUIRE(a.Cin <= 4 && a.Cout / 8 <= 256, CTDD_ERANGE, "first conv: Cin=%d Cout=%d", a.Cin, a.Cout);
+  CTDD_REQUIRE(a.Cin >= 1 && a.Cin <= 4 && a.Cout / 8 <= 256, CTDD_ERANGE, "first conv: Cin=%d Cout=%d", a.Cin, a.Cout);
   const int lanes = 256 / (a.Cout / 8);
   int gx = (a.H * a.W + 8 * lanes - 1) / (8 * lanes);     // ~8 pixels per thread
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(k_first_conv, dim3(gx, a.B), dim3(256), (size_t)2 * a.Cout * sizeof(double), (hipStream_t)stream, a);
+  const size_t lds = (size_t)2 * a.Cout * sizeof(double);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.Cin) {
+    case 1: hipLaunchKernelGGL(k_first_conv<1>, dim3(gx, a.B), dim3(256), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(k_first_conv<2>, dim3(gx, a.B), dim3(256), lds, st, a); break;
+    case 3: hipLaunchKernelGGL(k_first_conv<3>, dim3(gx, a.B), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL(k_first_conv<4>, dim3(gx, a.B), dim3(256), lds, st, a); break;
+  }
   return finish_launch("k_first_conv");
 }
 
@@ -888,13 +1678,19 @@ extern "C" int ctdd_unet_channel_stats(const float* x, int B, int HW, int C, dou
 extern "C" int ctdd_unet_time(const void* args_, const float* proj_w, const float* proj_b, int Ntot, float* proj_out,
                               void* stream) {
   const TimeArgs& a = *(const TimeArgs*)args_;
-  CTDD_REQUIRE(a.t && a.act && a.tdim % 4 == 0, CTDD_EINVAL, "bad time arguments");
+  CTDD_REQUIRE(a.t && a.act && a.hid && a.tdim % 16 == 0 && a.ch % 16 == 0, CTDD_EINVAL, "bad time arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_time_mlp, dim3(a.B), dim3(256), (size_t)(a.ch + a.tdim) * sizeof(float), st, a);
-  if (int rc = finish_launch("k_time_mlp")) return rc;
-  hipLaunchKernelGGL(k_time_proj, dim3((Ntot + 255) / 256, a.B), dim3(256), (size_t)a.tdim * sizeof(float), st,
+  const unsigned rb = (unsigned)((a.B + TRB - 1) / TRB);
+  auto lds = [](int K) { return (size_t)TRB * (K > 256 ? K : 256) * sizeof(float); };     // inputs, or the 4 x 16 x 64 partial sums
+  hipLaunchKernelGGL((k_rows_linear<true, true>), dim3((a.tdim + 63) / 64, rb), dim3(256), lds(a.ch), st,
+                     a.t, a.w1, a.b1, a.B, a.ch, a.tdim, a.hid);
+  if (int rc = finish_launch("k_rows_linear")) return rc;
+  hipLaunchKernelGGL((k_rows_linear<false, true>), dim3((a.tdim + 63) / 64, rb), dim3(256), lds(a.tdim), st,
+                     (const float*)a.hid, a.w2, a.b2, a.B, a.tdim, a.tdim, a.act);
+  if (int rc = finish_launch("k_rows_linear")) return rc;
+  hipLaunchKernelGGL((k_rows_linear<false, false>), dim3((Ntot + 63) / 64, rb), dim3(256), lds(a.tdim), st,
                      (const float*)a.act, proj_w, proj_b, a.B, a.tdim, Ntot, proj_out);
-  return finish_launch("k_time_proj");
+  return finish_launch("k_rows_linear");
 }
 
 extern "C" int ctdd_unet_attention(const void* args_, void* stream) {

@@ -48,7 +48,7 @@ class _GnArgs(C.Structure):
 
 class _TimeArgs(C.Structure):
     _fields_ = [("t", _P), ("B", _I), ("ch", _I), ("tdim", _I), ("w1", _P), ("b1", _P), ("w2", _P), ("b2", _P),
-                ("act", _P)]
+                ("hid", _P), ("act", _P)]
 
 
 class _AttnArgs(C.Structure):
@@ -66,7 +66,7 @@ def _lib():
     global _sigs_done
     lib = native.load()
     if not _sigs_done:
-        for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_patch", [_P, _I, _I, _I, _P]),
+        for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_patch", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_res", [_P, _I, _P]), ("ctdd_unet_conv_ring", [_P, _I, _P]),
                            ("ctdd_unet_upsample2x", [_P, _I, _I, _I, _I, _P, _P]), ("ctdd_unet_first_conv", [_P, _P]),
                            ("ctdd_unet_gn_apply", [_P, _P]), ("ctdd_unet_channel_stats", [_P, _I, _I, _I, _P, _P]),
                            ("ctdd_unet_time", [_P, _P, _P, _I, _P, _P]), ("ctdd_unet_attention", [_P, _P]),
@@ -155,11 +155,12 @@ class UNetEngine:
         def ptr(t):
             return None if t is None else t.data_ptr()
 
-        def launch(fn, *args):
+        def launch(fn, *args, label=None):
             def run():
                 rc = fn(*args, stream())
                 if rc != 0:
                     raise native.CtddError(f"{fn.__name__} failed ({rc}): {lib.ctdd_last_error().decode()}")
+            run.label = (fn.__name__, label)
             plan.append(run)
 
         bks = (32, 16) if self.precise else (96, 64, 32, 16)      # fp32 tiles: K = 32 keeps 4 workgroups per CU
@@ -212,7 +213,32 @@ class UNetEngine:
             keep.append(a)
             cs = [s[1] for s in segs]
             patchable = (not self.precise) and all(s[2] in (SEG_3x3, SEG_1x1) for s in segs) and Wout <= 33
-            if patchable:
+            hw_ = Hout * Wout
+            patchable = patchable and N % 8 == 0 and (hw_ >= 32 or hw_ == 16 or B == 1) and (logits_C == 0 or (N // logits_C) % 8 == 0)
+            M_ = B * Hout * Wout
+            lab = f"{Hout}x{Wout} K={w2d.shape[1]} N={N} segs={[(c_, k_) for _, c_, k_ in segs]}"
+            which = getattr(m, "conv_kernel", "auto")
+            only3 = all(s[2] == SEG_3x3 for s in segs)
+            if which == "auto":
+                # measured at batch 256 (MNIST net): the LDS-DMA ring wins where the grid fills the chip with
+                # 512-pixel tiles and every unit has nine taps; the 256-pixel patch kernel (two workgroups per CU)
+                # elsewhere
+                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= 256 and N % 96 == 0) else "patch"
+            resident = which == "res" and patchable and all(c % 32 == 0 for c in cs) and N % 32 == 0
+            ring = which == "ring" and patchable and all(c % 16 == 0 for c in cs) and N % 32 == 0
+            if resident or ring:
+                # 512-pixel tiles, all nine taps' weights in LDS: register-staged 32-channel units (k_conv_res)
+                # or an LDS-DMA ring of 16-channel units (k_conv_ring); csrc/unet_kernels.hip
+                bnt = 3 if N % 96 == 0 else 4 if (N % 128 == 0 and resident) else 2
+                ntiles = -(-M_ // 512) * -(-N // (32 * bnt))
+                units = sum(c // (32 if resident else 16) for c in cs)
+                if ntiles < 200 and units >= 2 and logits_C == 0:
+                    a.ksplit = max(1, min(units // 2, 512 // ntiles))
+                if a.ksplit > 1:
+                    zero_views.append((a, M_ * N))
+                fn = lib.ctdd_unet_conv_res if resident else lib.ctdd_unet_conv_ring
+                launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}")
+            elif patchable:
                 # throughput kernel: slab staged once per channel chunk (csrc/unet_kernels.hip: k_conv_patch)
                 if all(c % 48 == 0 for c in cs) and (N % 96 == 0 or N % 128 == 0):
                     bk, bnt = 48, (3 if N % 96 == 0 else 4)
@@ -222,7 +248,6 @@ class UNetEngine:
                     bk, bnt = 32, (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
                 else:
                     bk, bnt = 16, 1
-                M_ = B * Hout * Wout
                 wm = 64 if (bnt <= 3 and bk in (48, 64) and M_ >= 256 * 256) else 32
                 ntiles = -(-M_ // (4 * wm)) * -(-N // (32 * bnt))
                 units = sum(c // bk for c in cs)
@@ -230,11 +255,11 @@ class UNetEngine:
                     a.ksplit = max(1, min(units, -(-640 // ntiles)))
                 if a.ksplit > 1:
                     zero_views.append((a, M_ * N))
-                launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm)
+                launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm, label=lab + f" patch bk={bk} bnt={bnt} wm={wm} ks={a.ksplit}")
             else:
                 bk = pick_bk(cs)
                 bnt = pick_bnt(N, bk)
-                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise))
+                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}")
 
         def gn_apply(srcs, norm, swish, eps, HW):
             """srcs: one or two _Tensor; returns activated planes tensor."""
@@ -265,10 +290,11 @@ class UNetEngine:
         st.tact = torch.empty((B, tdim), dtype=torch.float32, device=dev)
         st.tproj = torch.empty((B, Ntot), dtype=torch.float32, device=dev)
         ta = _TimeArgs()
-        tw = [net.time[1].weight, net.time[1].bias, net.time[3].weight, net.time[3].bias]
+        tw = [net.time[1].weight.t(), net.time[1].bias, net.time[3].weight.t(), net.time[3].bias]      # weights as [in][out]
         tw = [w.detach().float().contiguous() for w in tw]
+        st.thid = torch.empty((B, tdim), dtype=torch.float32, device=dev)
         ta.t, ta.B, ta.ch, ta.tdim = ptr(st.t_in), B, ch, tdim
-        ta.w1, ta.b1, ta.w2, ta.b2, ta.act = ptr(tw[0]), ptr(tw[1]), ptr(tw[2]), ptr(tw[3]), ptr(st.tact)
+        ta.w1, ta.b1, ta.w2, ta.b2, ta.hid, ta.act = ptr(tw[0]), ptr(tw[1]), ptr(tw[2]), ptr(tw[3]), ptr(st.thid), ptr(st.tact)
         keep.extend(tw + [pw, pb, ta])
         launch(lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
         toff = {}

@@ -37,6 +37,12 @@ int ctdd_unet_conv(const void* conv_args, int bk, int bnt, int f32, void* stream
 /* bf16 throughput kernel for stride-1 3x3 / 1x1 segments: the input slab of a pixel tile is staged in
  * LDS once per channel chunk and shared by the nine taps; bk in {48,64,32,16}, wm = rows per wave */
 int ctdd_unet_conv_patch(const void* conv_args, int bk, int bnt, int wm, void* stream);
+/* same contract, 512-pixel tiles with the weights of all nine taps of a 32-channel chunk resident in LDS
+ * (no barrier between taps); segment channel counts must be multiples of 32; bnt in {2,3,4} */
+int ctdd_unet_conv_res(const void* conv_args, int bnt, void* stream);
+/* same contract, 16-channel units moved global -> LDS by LDS-DMA into a ring of unit buffers (no staging
+ * registers, one barrier per unit); segment channel counts must be multiples of 16; bnt in {2,3,4} */
+int ctdd_unet_conv_ring(const void* conv_args, int bnt, void* stream);
 int ctdd_unet_upsample2x(const void* x_bf16, int B, int H, int W, int C, void* out_bf16, void* stream);   /* unet.py:79-85 */
 
 typedef struct {
@@ -56,7 +62,9 @@ int ctdd_unet_gn_apply(const void* gn_args, void* stream);
 int ctdd_unet_channel_stats(const float* x, int B, int HW, int C, double* stats, void* stream);
 
 typedef struct {
-  const float* t; int B, ch, tdim; const float* w1; const float* b1; const float* w2; const float* b2; float* act;
+  const float* t; int B, ch, tdim;
+  const float* w1; const float* b1; const float* w2; const float* b2;   /* Linear weights transposed to [in][out] */
+  float* hid; float* act;                                                /* [B][tdim] scratch, [B][tdim] = swish(temb) */
 } ctdd_time_args;
 /* sinusoid -> Linear -> Swish -> Linear -> Swish, then every ResBlock's time projection (unet.py:223-241,332-337,110);
  * proj_w = the concatenated projection weights transposed to [tdim][Ntot] */

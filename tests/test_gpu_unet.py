@@ -90,3 +90,66 @@ def test_engine_matches_module_mnist():
     assert (out - ref).abs().max().item() < 2e-4 * max(scale, 1.0)
     assert (fast - ref).abs().max().item() < 5e-2 * scale
     model.train()
+
+
+def _conv_case(B, H, W, segs, N, ksplit, seed):
+    """Random NHWC bf16 segments + [N][K] weights; returns (args builder inputs, fp32 torch reference)."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    srcs, ws, ref = [], [], 0.0
+    for C_, kind in segs:
+        x = torch.randn((B, H, W, C_), generator=g, device="cuda").to(torch.bfloat16)
+        k = 3 if kind == 0 else 1
+        w = (torch.randn((N, C_, k, k), generator=g, device="cuda") / (C_ * k * k) ** 0.5).to(torch.bfloat16)
+        ref = ref + F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=k // 2)
+        srcs.append(x.contiguous())
+        ws.append(w.float().permute(0, 2, 3, 1).reshape(N, -1))
+    w2d = torch.cat(ws, 1).to(torch.bfloat16).contiguous()
+    bias = torch.randn((N,), generator=g, device="cuda")
+    tb = torch.randn((B, N), generator=g, device="cuda")
+    res = torch.randn((B, H, W, N), generator=g, device="cuda").to(torch.bfloat16).contiguous()
+    ref = ref.permute(0, 2, 3, 1) + bias + tb[:, None, None, :] + res.float()
+    return srcs, w2d, bias, tb, res, ref
+
+
+@pytest.mark.parametrize("B,H,W,segs,N,ksplit,bnt", [
+    (5, 28, 28, [(96, 0)], 96, 1, 3),                       # 3x3, ragged last tile (3920 pixels)
+    (3, 14, 14, [(192, 0), (96, 1), (96, 1)], 192, 2, 3),   # ResBlock conv2 with the folded 1x1 skip on two sources, split-K
+    (4, 7, 7, [(192, 0)], 192, 3, 3),                       # 7x7 level, tiles spanning several samples
+    (2, 28, 28, [(96, 0)], 256, 1, 4),                      # output conv shape (N = 256)
+    (2, 16, 16, [(64, 0), (64, 1)], 64, 1, 2),
+    (2, 28, 28, [(16, 0)], 96, 1, 3),                       # a single unit
+    (3, 14, 14, [(48, 1), (32, 0)], 96, 1, 3),              # 1x1 units first, then 3x3
+])
+@pytest.mark.parametrize("kernel", ["ctdd_unet_conv_res", "ctdd_unet_conv_ring"])
+def test_slab_conv_kernels(kernel, B, H, W, segs, N, ksplit, bnt):
+    """The slab convolution kernels (weights of all nine taps resident in LDS; register-staged 32-channel
+    units or LDS-DMA ring of 16-channel units) against an fp32 torch convolution of the same bf16-rounded
+    operands, with bias + per-sample bias + residual and the GroupNorm statistics."""
+    if kernel == "ctdd_unet_conv_res" and any(c % 32 for c, _ in segs):
+        pytest.skip("register-staged kernel needs 32-channel units")
+    import ctypes as C
+    from ctdd import unet_engine as ue
+    lib = ue._lib()
+    srcs, w2d, bias, tb, res, ref = _conv_case(B, H, W, segs, N, ksplit, seed=B * 100 + H)
+    M = B * H * W
+    a = ue._ConvArgs()
+    a.nseg = len(segs)
+    for i, ((C_, kind), x) in enumerate(zip(segs, srcs)):
+        a.seg[i].hi, a.seg[i].C, a.seg[i].kind = x.data_ptr(), C_, kind
+    a.w_hi, a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = w2d.data_ptr(), B, H, W, H, W, N, w2d.shape[1]
+    a.bias, a.tbias, a.tb_stride, a.res_bf16 = bias.data_ptr(), tb.data_ptr(), N, res.data_ptr()
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    out_hi = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros((B, N, 2), dtype=torch.float64, device="cuda")
+    acc = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    a.out_f32, a.out_hi, a.stats, a.ksplit, a.acc_buf = out.data_ptr(), out_hi.data_ptr(), stats.data_ptr(), ksplit, acc.data_ptr()
+    rc = getattr(lib, kernel)(C.byref(a), bnt, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.ctdd_last_error().decode()
+    torch.cuda.synchronize()
+    ref2 = ref.reshape(M, N)
+    # exact products (bf16 x bf16 in fp32), fp32 accumulation in a different order: ~1e-6 relative
+    assert (out - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+    assert torch.equal(out_hi, out.to(torch.bfloat16))
+    want = torch.stack([out.double().view(B, H * W, N).sum(1), (out.double() ** 2).view(B, H * W, N).sum(1)], -1)
+    torch.testing.assert_close(stats, want, rtol=1e-12, atol=1e-9)
