@@ -1288,10 +1288,17 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnArgs a) {
       x[6] = __uint_as_float(u.w << 16); x[7] = __uint_as_float(u.w & 0xFFFF0000u);
     }
     float y[8];
+    const float4 sc0 = *(const float4*)(scale + c0), sc1 = *(const float4*)(scale + c0 + 4);
+    const float4 sh0 = *(const float4*)(shift + c0), sh1 = *(const float4*)(shift + c0 + 4);
+    const float scv[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+    const float shv[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      y[j] = fmaf(x[j], scale[c0 + j], shift[c0 + j]);
-      if (a.swish) y[j] = y[j] / (1.0f + expf(-y[j]));
+      y[j] = fmaf(x[j], scv[j], shv[j]);
+      if (a.swish) {
+        if (a.out_f32) y[j] = y[j] / (1.0f + expf(-y[j]));                       // fp32 mode: exact
+        else y[j] = y[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[j]));           // bf16 outputs: hardware exp2 / rcp (1 ulp)
+      }
     }
     const size_t oo = ((size_t)b * a.HW + px) * C + c0;
     if (a.out_hi)
@@ -1663,8 +1670,9 @@ extern "C" int ctdd_unet_gn_apply(const void* args_, void* stream) {
   const int C = a.C1 + a.C2;
   CTDD_REQUIRE(C % 8 == 0 && a.C1 % 8 == 0 && C % a.G == 0 && (a.out_hi || a.out_f32), CTDD_EINVAL, "bad GroupNorm arguments");
   const int64_t nv = (int64_t)a.HW * (C / 8);
-  int gx = (int)((nv + 255) / 256);
+  int gx = (int)((nv + 2047) / 2048);      // >= 8 vectors per thread: the per-workgroup scale/shift prologue (fp64 divide + sqrt) stays small
   if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
   hipLaunchKernelGGL(k_gn_apply, dim3(gx, a.B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, a);
   return finish_launch("k_gn_apply");
 }

@@ -220,10 +220,10 @@ class UNetEngine:
             which = getattr(m, "conv_kernel", "auto")
             only3 = all(s[2] == SEG_3x3 for s in segs)
             if which == "auto":
-                # measured at batch 256 (MNIST net): the LDS-DMA ring wins where the grid fills the chip with
-                # 512-pixel tiles and every unit has nine taps; the 256-pixel patch kernel (two workgroups per CU)
-                # elsewhere
-                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= 256 and N % 96 == 0) else "patch"
+                # measured at batch 256 (MNIST net): the LDS-DMA ring wins where 512-pixel tiles give >= 160
+                # workgroups and every unit has nine taps (28x28, 14x14); the patch kernel (128/256-pixel tiles, two
+                # workgroups per CU) elsewhere.  Split-K lost everywhere it was tried (fp32 atomics + finish pass).
+                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= 160 and N % 96 == 0) else "patch"
             resident = which == "res" and patchable and all(c % 32 == 0 for c in cs) and N % 32 == 0
             ring = which == "ring" and patchable and all(c % 16 == 0 for c in cs) and N % 32 == 0
             if resident or ring:
@@ -232,8 +232,8 @@ class UNetEngine:
                 bnt = 3 if N % 96 == 0 else 4 if (N % 128 == 0 and resident) else 2
                 ntiles = -(-M_ // 512) * -(-N // (32 * bnt))
                 units = sum(c // (32 if resident else 16) for c in cs)
-                if ntiles < 200 and units >= 2 and logits_C == 0:
-                    a.ksplit = max(1, min(units // 2, 512 // ntiles))
+                if getattr(m, "conv_ksplit", 1) > 1 and units >= 2 and logits_C == 0:
+                    a.ksplit = min(units, int(m.conv_ksplit))
                 if a.ksplit > 1:
                     zero_views.append((a, M_ * N))
                 fn = lib.ctdd_unet_conv_res if resident else lib.ctdd_unet_conv_ring
@@ -248,11 +248,10 @@ class UNetEngine:
                     bk, bnt = 32, (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
                 else:
                     bk, bnt = 16, 1
-                wm = 64 if (bnt <= 3 and bk in (48, 64) and M_ >= 256 * 256) else 32
-                ntiles = -(-M_ // (4 * wm)) * -(-N // (32 * bnt))
+                wm = 64 if (bnt <= 3 and bk in (48, 64) and M_ >= 196 * 256) else 32
                 units = sum(c // bk for c in cs)
-                if ntiles < 384 and units >= 2 and logits_C == 0 and out_f32_tensor is None:
-                    a.ksplit = max(1, min(units, -(-640 // ntiles)))
+                if getattr(m, "conv_ksplit", 1) > 1 and units >= 2 and logits_C == 0 and out_f32_tensor is None:
+                    a.ksplit = min(units, int(m.conv_ksplit))
                 if a.ksplit > 1:
                     zero_views.append((a, M_ * N))
                 launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm, label=lab + f" patch bk={bk} bnt={bnt} wm={wm} ks={a.ksplit}")
