@@ -893,36 +893,49 @@ __global__ __launch_bounds__(512) void k_conv_ring(const ConvArgs a) {
     }
   }
 
-  // ---- unit order of this z-slice: all 16-channel units of 3x3 segments, then those of 1x1 segments
+  // ---- unit order of this z-slice: all 16-channel units of 3x3 segments, then those of 1x1 segments.
+  // The segment table is read from the kernel arguments ONCE, into scalars (a scalar load inside the
+  // unit loop costs its latency on every unit, inside the tap loop it would also drain the LDS queue).
+  const unsigned char* sg_hi[3];
+  int sg_C[3], sg_nu[3], sg_k[3];                                // channels, units, K offset of the segment's tap 0
+  bool sg_one[3];
   int n33 = 0, n11 = 0;
-  for (int sgi = 0; sgi < a.nseg; ++sgi) {
-    if (a.seg[sgi].kind == SEG_1x1) n11 += a.seg[sgi].C / BK;
-    else n33 += a.seg[sgi].C / BK;
+  {
+    int kk = 0;
+#pragma unroll
+    for (int sgi = 0; sgi < 3; ++sgi) {
+      const bool on = sgi < a.nseg;
+      sg_hi[sgi] = (const unsigned char*)a.seg[on ? sgi : 0].hi;
+      sg_C[sgi] = on ? a.seg[sgi].C : 0;
+      sg_one[sgi] = on && a.seg[sgi].kind == SEG_1x1;
+      sg_nu[sgi] = sg_C[sgi] / BK;
+      sg_k[sgi] = kk;
+      kk += sg_C[sgi] * (sg_one[sgi] ? 1 : 9);
+      if (sg_one[sgi]) n11 += sg_nu[sgi]; else n33 += sg_nu[sgi];
+    }
   }
   const int nunits = n33 + n11;
   const int zs = blockIdx.z, nz = a.ksplit > 1 ? a.ksplit : 1;
   const int myunits = zs < nunits ? (nunits - zs + nz - 1) / nz : 0;     // sorted units zs, zs+nz, ...
+  const unsigned char* const w_base = (const unsigned char*)a.w_hi;
 
-  // Everything a DMA op needs from the segment table, fetched once per unit (scalar loads inside
-  // the tap loop would make every tap wait for lgkmcnt(0), i.e. for its own prefetched fragments).
   struct Unit { const unsigned char* src; const unsigned char* wsrc; int C; bool one; };
   auto unit_info = [&](int su) {                                 // su = index in the sorted order
     const bool one = su >= n33;
     int u = one ? su - n33 : su;
-    Unit r = {nullptr, nullptr, 16, one};
-    int k = 0;
-    for (int sgi = 0; sgi < a.nseg; ++sgi) {
-      const bool sone = a.seg[sgi].kind == SEG_1x1;
-      const int nu = a.seg[sgi].C / BK;
-      if (sone == one && u >= 0 && u < nu) {
-        r.C = a.seg[sgi].C;
-        r.src = (const unsigned char*)(a.seg[sgi].hi + u * BK);          // channel chunk of the segment's tensor
-        r.wsrc = (const unsigned char*)(a.w_hi + k + u * BK);            // its K offset in a weight row (tap 0)
-        u = -1;
-      } else if (sone == one && u >= 0) {
-        u -= nu;
+    Unit r = {sg_hi[0], w_base, 16, one};
+    bool found = false;
+#pragma unroll
+    for (int sgi = 0; sgi < 3; ++sgi) {
+      const bool mine = !found && sg_one[sgi] == one && sg_nu[sgi] > 0 && u < sg_nu[sgi];
+      if (mine) {
+        r.C = sg_C[sgi];
+        r.src = sg_hi[sgi] + (size_t)u * BK * 2;                         // channel chunk of the segment's tensor
+        r.wsrc = w_base + (size_t)(sg_k[sgi] + u * BK) * 2;              // its K offset in a weight row (tap 0)
+        found = true;
+      } else if (!found && sg_one[sgi] == one) {
+        u -= sg_nu[sgi];
       }
-      k += a.seg[sgi].C * (sone ? 1 : 9);
     }
     return r;
   };
@@ -1535,7 +1548,7 @@ extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, 
 #define CASEP(BK_, BNT_, WM_) if (bk == BK_ && bnt == BNT_ && wm == WM_) return launch_patch<BK_, BNT_, WM_>(a, st);
   CASEP(48, 3, 64) CASEP(48, 3, 32) CASEP(48, 4, 64) CASEP(48, 4, 32)
   CASEP(64, 4, 64) CASEP(64, 4, 32) CASEP(64, 2, 64) CASEP(64, 2, 32) CASEP(32, 1, 32) CASEP(32, 3, 32) CASEP(32, 4, 32)
-  CASEP(16, 1, 32)
+  CASEP(16, 1, 32) CASEP(48, 1, 32) CASEP(48, 2, 32) CASEP(64, 1, 32) CASEP(32, 2, 32) CASEP(48, 2, 64)
 #undef CASEP
   CTDD_REQUIRE(false, CTDD_ERANGE, "no patch-conv instantiation for BK=%d BNT=%d WM=%d", bk, bnt, wm);
 }

@@ -240,7 +240,12 @@ class UNetEngine:
                 launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}")
             elif patchable:
                 # throughput kernel: slab staged once per channel chunk (csrc/unet_kernels.hip: k_conv_patch)
-                if all(c % 48 == 0 for c in cs) and (N % 96 == 0 or N % 128 == 0):
+                small = -(-M_ // 128) * -(-N // 96) < 256            # too few 128 x 96 tiles to fill the chip: 32-column tiles
+                if small and all(c % 64 == 0 for c in cs) and N % 32 == 0:
+                    bk, bnt = 64, 1
+                elif small and all(c % 48 == 0 for c in cs) and N % 32 == 0:
+                    bk, bnt = 48, 1
+                elif all(c % 48 == 0 for c in cs) and (N % 96 == 0 or N % 128 == 0):
                     bk, bnt = 48, (3 if N % 96 == 0 else 4)
                 elif all(c % 64 == 0 for c in cs) and N % 64 == 0:
                     bk, bnt = 64, (4 if N % 128 == 0 else 2)
@@ -248,7 +253,7 @@ class UNetEngine:
                     bk, bnt = 32, (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
                 else:
                     bk, bnt = 16, 1
-                wm = 64 if (bnt <= 3 and bk in (48, 64) and M_ >= 196 * 256) else 32
+                wm = 64 if (bnt >= 2 and bk in (48, 64) and M_ >= 196 * 256 and (bk, bnt) != (64, 4)) else 32
                 units = sum(c // bk for c in cs)
                 if getattr(m, "conv_ksplit", 1) > 1 and units >= 2 and logits_C == 0 and out_f32_tensor is None:
                     a.ksplit = min(units, int(m.conv_ksplit))
