@@ -11,9 +11,13 @@ weights) are resident in HBM before the timed region.  Sampling shards over GPUs
 data-path collective: weak scaling, value = all ranks' sample-steps / max-rank time.
 
 The JSON line also carries
-  roofline      the fused tau-leap kernel: algorithmic bytes per sample-step (809 088 B at fp32,
-                SURVEY 8d) x batch / its mean launch duration (HIP events on the launch stream);
-  cpu_baseline  the CPU oracle (checker, never the product) running the same step on host cores.
+  roofline          the fused tau-leap kernel k_tauleap_s256: algorithmic bytes per sample-step
+                    (809 088 B at fp32) x batch / its mean launch duration (HIP events on
+                    the launch stream); `mfma_view` prices the same launches by their matrix FLOPs
+                    (3 split-bf16 products of the D x S x S contraction);
+  roofline_network  the score network's convolution launches (the larger share of the step):
+                    2 M N K matrix FLOPs / their summed launch durations vs the dense bf16 MFMA peak;
+  cpu_baseline      the CPU oracle (checker, never the product) running the same step on host cores.
 """
 import argparse
 import json
@@ -31,6 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 (no sparsity)
 D, S = 784, 256
 ALGO_BYTES_PER_SAMPLE_STEP = D * S * 4 + D * 4 + D * 4      # fp32 logits + x in + x out
 
@@ -80,9 +85,44 @@ def kernel_roofline(sampler, st, steps, batch):
         times.append(e0.elapsed_time(e1) * 1e-3)
     dur = float(np.mean(times))
     achieved = ALGO_BYTES_PER_SAMPLE_STEP * batch / dur / 1e9
+    mfma_flops = 3 * 2 * D * S * S * batch                     # hi*hi + hi*lo + lo*hi products of the S x S contraction
     return {"kernel": "ctdd k_tauleap_s256 (fused softmax + split-bf16 MFMA contraction + Poisson draw + update)", "bound": "hbm", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch}
+            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch,
+            "mfma_view": {"achieved": round(mfma_flops / dur / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(mfma_flops / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
+
+
+def network_roofline(model, batch):
+    """The U-Net engine's convolution launches replayed one by one (eager, outside the HIP graph) with HIP
+    events on the launch stream: summed 2*M*N*K matrix FLOPs / summed durations."""
+    eng = getattr(model, "_engine", None)
+    if eng is None:
+        return None
+    plans = [st for (b, _), st in eng._plans.items() if b == batch]
+    if not plans:
+        return None
+    st = plans[0]
+    eng._run_plan(st)
+    torch.cuda.synchronize()
+    flops, secs, n = 0, 0.0, 0
+    for step in st.plan:
+        if not getattr(step, "flops", 0):
+            continue
+        step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            step()
+        e1.record()
+        e1.synchronize()
+        secs += e0.elapsed_time(e1) * 1e-3 / 3
+        flops += step.flops
+        n += 1
+    ach = flops / secs / 1e12
+    return {"kernel": "ctdd k_conv_ring / k_conv_patch / k_conv_igemm (bf16 implicit-GEMM convolutions of the score network)", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5),
+            "traffic": None, "launches_per_forward": n, "sum_launch_us": round(secs * 1e6, 1), "matrix_gflop_per_forward": round(flops / 1e9, 1)}
 
 
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
@@ -164,18 +204,20 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         roof = kernel_roofline(sampler, st, range(W + K, min(W + K + 20, sampler.num_steps - 1)), a.batch) if rank == 0 else None
+        roof_net = network_roofline(model, a.batch) if rank == 0 else None
     if rank == 0:
         value = a.batch * K * world / el
         line = {
             "metric": "tau-leaping sample-steps/s", "value": round(value, 2), "unit": "sample-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 score network (fp32 accumulate) + f32 rates/softmax with split-bf16 MFMA contraction", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
+            "dtype": "bf16", "dtype_detail": "bf16 score network (fp32 accumulate) + f32 rates/softmax with split-bf16 MFMA contraction", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
             "config": {"workload": "MNIST tauLDR U-Net TauL step (config_tauUnet_mnist: D=784, S=256, 1000-step grid)",
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "D": D, "S": S,
                        "parallelism": f"sample-sharded x{world}, no collective in the loop"},
             "dims_per_s": round(value * D, 1),
             "roofline": roof,
+            "roofline_network": roof_net,
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, cfg, a.cpu_batch)

@@ -855,17 +855,17 @@ __global__ __launch_bounds__(512) void k_conv_res(const ConvArgs a) {
 // computed once per kernel, and a DMA op is one vector instruction on a scalar base.  Units of
 // 1x1 segments run in a second, rolled loop after all 3x3 units (two loops instead of one
 // branchy body keep the accumulators in place).
-template <int BNT, int NBUF>
-__global__ __launch_bounds__(512) void k_conv_ring(const ConvArgs a) {
-  constexpr int BK = 16, WM = 64, MT = 2, NW = 8;
+template <int BNT, int NBUF, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const ConvArgs a) {
+  constexpr int BK = 16, WM = 64, MT = 2;
   constexpr int BN = 32 * BNT, BMP = NW * WM;
-  constexpr int SP = 19;                                         // slab pieces: 608 rows >= 512 + 2*(33+1)
+  constexpr int SP = (BMP + 2 * 34 + 31) / 32;                   // slab pieces of 32 rows >= BMP + 2*(33+1) rows
   constexpr int SLABB = SP * 1024, BUFB = SLABB + 9 * BN * 32;
   constexpr int OPS3 = (SP + 9 * BNT + NW - 1) / NW;             // DMA ops per wave for a 3x3 unit
-  constexpr int OPS1 = (16 + BNT + NW - 1) / NW;                 // ... for a 1x1 unit (512 rows, one tap)
+  constexpr int OPS1 = (BMP / 32 + BNT + NW - 1) / NW;           // ... for a 1x1 unit (BMP rows, one tap)
   constexpr int DEPTH = NBUF - 1;                                // units in flight ahead of the one computed
   static_assert(DEPTH == 1 || DEPTH == 2, "ring of two or three unit buffers");
-  static_assert(OPS3 <= 9, "one DMA op per tap");
+  static_assert(OPS3 <= 18, "at most two DMA ops per tap");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(512) void k_conv_ring(const ConvArgs a) {
   const unsigned swz16 = (unsigned)(((lane & 1) ^ ((rl >> 3) & 1)) << 4);   // byte offset of the lane's half
   const unsigned wlane = (unsigned)rl * (unsigned)Ktot * 2u + swz16;
   auto issue_op = [&](const Unit& un, unsigned slane, int buf, int j) {      // slane = rl * C * 2 + swz16 for un.C
-    const int nsp = un.one ? 16 : SP;
+    const int nsp = un.one ? BMP / 32 : SP;
     const int total = nsp + (un.one ? BNT : 9 * BNT);
     int p = wave + NW * j;
     p = p < total ? p : total - 1;
@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(512) void k_conv_ring(const ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if (tap + 1 < 9) read_frags(sb + aoff[tap + 1], sb + boff + (tap + 1) * BN * 32, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
       if (tap < OPS3 && tap < nops) issue_op(nxt, nsl, nbuf, tap);
+      if (tap + 9 < OPS3 && tap + 9 < nops) issue_op(nxt, nsl, nbuf, tap + 9);
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(fa[tap & 1], fb[tap & 1]);
       __builtin_amdgcn_sched_barrier(0);
@@ -1601,21 +1602,22 @@ extern "C" int ctdd_unet_conv_res(const void* args_, int bnt, void* stream) {
   CTDD_REQUIRE(false, CTDD_ERANGE, "unsupported resident conv tile bnt=%d", bnt);
 }
 
-template <int BNT, int NBUF>
+template <int BNT, int NBUF, int NW>
 static int launch_ring(const ConvArgs& a, hipStream_t st) {
+  constexpr int BMP = NW * 64, SP = (BMP + 2 * 34 + 31) / 32;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   const int nz = a.ksplit > 1 ? a.ksplit : 1;
-  dim3 g((unsigned)((M + 511) / 512), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), (unsigned)nz);
-  size_t lds = (size_t)NBUF * (19 * 1024 + 9 * 32 * BNT * 32);
-  const size_t epi_lds = epilogue_rows_lds(8, BNT, 512, a.H * a.W);
+  dim3 g((unsigned)((M + BMP - 1) / BMP), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), (unsigned)nz);
+  size_t lds = (size_t)NBUF * (SP * 1024 + 9 * 32 * BNT * 32);
+  const size_t epi_lds = epilogue_rows_lds(NW, BNT, BMP, a.H * a.W);
   if (lds < epi_lds) lds = epi_lds;
   CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "ring conv: %zu bytes of LDS", lds);
   static bool attr_done = false;               // not inside a stream capture: set once per instantiation
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_conv_ring<BNT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_conv_ring<BNT, NBUF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_conv_ring<BNT, NBUF>), g, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((k_conv_ring<BNT, NBUF, NW>), g, dim3(NW * 64), lds, st, a);
   if (int rc = finish_launch("k_conv_ring")) return rc;
   if (nz > 1) {
     hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
@@ -1642,10 +1644,12 @@ extern "C" int ctdd_unet_conv_ring(const void* args_, int bnt, void* stream) {
   CTDD_REQUIRE((int64_t)a.Ktot * 64 < (int64_t)1 << 31, CTDD_ERANGE, "ring conv: Ktot=%d too large for 32-bit lane offsets", a.Ktot);
   CTDD_REQUIRE(a.ksplit <= 1 || (a.acc_buf && a.logits_C == 0), CTDD_EINVAL, "split-K needs acc_buf");
   hipStream_t st = (hipStream_t)stream;
-  switch (bnt) {
-    case 2: return launch_ring<2, 3>(a, st);
-    case 3: return launch_ring<3, 3>(a, st);
-    case 4: return launch_ring<4, 2>(a, st);
+  switch (bnt) {                            // bnt + 10: 256-pixel tiles, four waves, two workgroups per CU, ring of two
+    case 2: return launch_ring<2, 3, 8>(a, st);
+    case 3: return launch_ring<3, 3, 8>(a, st);
+    case 4: return launch_ring<4, 2, 8>(a, st);
+    case 12: return launch_ring<2, 2, 4>(a, st);
+    case 13: return launch_ring<3, 2, 4>(a, st);
   }
   CTDD_REQUIRE(false, CTDD_ERANGE, "unsupported ring conv tile bnt=%d", bnt);
 }

@@ -155,12 +155,13 @@ class UNetEngine:
         def ptr(t):
             return None if t is None else t.data_ptr()
 
-        def launch(fn, *args, label=None):
+        def launch(fn, *args, label=None, flops=0):
             def run():
                 rc = fn(*args, stream())
                 if rc != 0:
                     raise native.CtddError(f"{fn.__name__} failed ({rc}): {lib.ctdd_last_error().decode()}")
             run.label = (fn.__name__, label)
+            run.flops = flops                      # matrix FLOPs of the launch (bench.py's network roofline)
             plan.append(run)
 
         bks = (32, 16) if self.precise else (96, 64, 32, 16)      # fp32 tiles: K = 32 keeps 4 workgroups per CU
@@ -237,7 +238,7 @@ class UNetEngine:
                 if a.ksplit > 1:
                     zero_views.append((a, M_ * N))
                 fn = lib.ctdd_unet_conv_res if resident else lib.ctdd_unet_conv_ring
-                launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}")
+                launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}", flops=2 * M_ * N * w2d.shape[1])
             elif patchable:
                 # throughput kernel: slab staged once per channel chunk (csrc/unet_kernels.hip: k_conv_patch)
                 small = -(-M_ // 128) * -(-N // 96) < 256            # too few 128 x 96 tiles to fill the chip: 32-column tiles
@@ -259,11 +260,12 @@ class UNetEngine:
                     a.ksplit = min(units, int(m.conv_ksplit))
                 if a.ksplit > 1:
                     zero_views.append((a, M_ * N))
-                launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm, label=lab + f" patch bk={bk} bnt={bnt} wm={wm} ks={a.ksplit}")
+                launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm, label=lab + f" patch bk={bk} bnt={bnt} wm={wm} ks={a.ksplit}",
+                       flops=2 * M_ * N * w2d.shape[1])
             else:
                 bk = pick_bk(cs)
                 bnt = pick_bnt(N, bk)
-                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}")
+                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}", flops=2 * M_ * N * w2d.shape[1])
 
         def gn_apply(srcs, norm, swish, eps, HW):
             """srcs: one or two _Tensor; returns activated planes tensor."""

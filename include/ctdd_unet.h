@@ -41,7 +41,8 @@ int ctdd_unet_conv_patch(const void* conv_args, int bk, int bnt, int wm, void* s
  * (no barrier between taps); segment channel counts must be multiples of 32; bnt in {2,3,4} */
 int ctdd_unet_conv_res(const void* conv_args, int bnt, void* stream);
 /* same contract, 16-channel units moved global -> LDS by LDS-DMA into a ring of unit buffers (no staging
- * registers, one barrier per unit); segment channel counts must be multiples of 16; bnt in {2,3,4} */
+ * registers, one barrier per unit); segment channel counts must be multiples of 16; bnt in {2,3,4}: 512-pixel
+ * tiles, eight waves; bnt in {12,13}: N-tile 64/96 with 256-pixel tiles, four waves, two workgroups per CU */
 int ctdd_unet_conv_ring(const void* conv_args, int bnt, void* stream);
 int ctdd_unet_upsample2x(const void* x_bf16, int B, int H, int W, int C, void* out_bf16, void* stream);   /* unet.py:79-85 */
 
