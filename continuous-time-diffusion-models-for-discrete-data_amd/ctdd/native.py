@@ -47,6 +47,8 @@ _SIGS = {
     "ctdd_s256_step_table_bytes": ([], _I64),
     "ctdd_s256_prepare": ([_P, _P, _F, _I, _P, _P, _P, _P], _I),
     "ctdd_tauleap_step_s256": ([_P, _P, _P, _P, _P, _P, _F, _F, _U32, _U64, _U64, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_opt_chunk_elems": ([], _I),
+    "ctdd_adam_ema_step": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
 }
 UNET_EXPORTS = ("ctdd_unet_conv", "ctdd_unet_conv_patch", "ctdd_unet_conv_res", "ctdd_unet_conv_ring", "ctdd_unet_upsample2x", "ctdd_unet_first_conv", "ctdd_unet_gn_apply", "ctdd_unet_channel_stats",
                 "ctdd_unet_time", "ctdd_unet_attention", "ctdd_unet_logistic_head")    # bound in ctdd/unet_engine.py

@@ -130,11 +130,15 @@ class EMA:
     def init_ema(self):
         self.shadow_params = [p.clone().detach() for p in self._trainable()]
 
-    def update_ema(self):
+    def next_ema_decay(self):
+        """Count one update and return its decay (models.py:745-750)."""
         if len(self.shadow_params) == 0:
             raise ValueError("Shadow params not initialized before first ema update!")
         self.num_updates += 1
-        decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        return min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+
+    def update_ema(self):
+        decay = self.next_ema_decay()
         with torch.no_grad():
             params = self._trainable()
             # shadow -= (1-decay) * (shadow - param), one fused multi-tensor launch

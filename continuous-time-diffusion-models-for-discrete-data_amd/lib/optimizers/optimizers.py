@@ -1,9 +1,85 @@
-"""Optimizer registry entries (reference lib/optimizers/optimizers.py:4-6: plain Adam(params, lr))."""
+"""Optimizer registry entries (reference lib/optimizers/optimizers.py:4-6: plain Adam(params, lr)).
+
+`Adam` is torch.optim.Adam (same constructor defaults, same `state_dict` layout, so reference
+checkpoints load) plus `fused_step`: gradient clipping, the Adam update and the EMA shadow update of
+ALL parameter tensors in two libctdd launches (csrc/optim.hip, K28).  `Standard.step` takes that path
+whenever the parameters live on a GPU; it fails loudly if libctdd is missing."""
+import ctypes as C
+
 import torch
 
 import lib.optimizers.optimizers_utils as optimizers_utils
 
 
+class _OptTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p),
+                ("n", C.c_int64)]
+
+
+class _OptChunk(C.Structure):
+    _fields_ = [("tensor", C.c_int), ("pad", C.c_int), ("start", C.c_int64)]
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr):
+        super().__init__(params, lr)
+        self._tables = None          # (key, tensors_dev, chunks_dev, nchunks)
+        self._scratch = None
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:             # torch.optim.Adam's lazy state initialisation
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def fused_step(self, max_norm=0.0, shadow_params=None, ema_decay=-1.0, all_params=None):
+        """clip_grad_norm_(max_norm) -> Adam step -> shadow lerp for every parameter that has a gradient.
+        shadow_params is aligned with `all_params` (the model's trainable parameters in order)."""
+        from ctdd import native
+        lib = native.load()
+        for group in self.param_groups:
+            if group["weight_decay"] != 0 or group["amsgrad"] or group["maximize"]:
+                raise native.CtddError("fused_step implements plain Adam (no weight decay / amsgrad / maximize)")
+            shadow_of = {}
+            if shadow_params is not None:
+                shadow_of = {id(p): s for p, s in zip(all_params, shadow_params)}
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            rows, key = [], []
+            for p in ps:
+                st = self._ensure_state(p)
+                g, m, v, s = p.grad, st["exp_avg"], st["exp_avg_sq"], shadow_of.get(id(p))
+                for t, nm in ((p, "parameter"), (g, "gradient"), (m, "exp_avg"), (v, "exp_avg_sq")) + (((s, "shadow"),) if s is not None else ()):
+                    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                        raise native.CtddError(f"fused_step: {nm} must be a contiguous fp32 GPU tensor (got {t.dtype} on {t.device})")
+                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), s.data_ptr() if s is not None else 0, p.numel()))
+                key.append(rows[-1])
+            key = tuple(key)
+            dev = ps[0].device
+            if self._tables is None or self._tables[0] != key:
+                ce = lib.ctdd_opt_chunk_elems()
+                tt = (_OptTensor * len(rows))(*[_OptTensor(*r) for r in rows])
+                chunks = [(i, 0, s0) for i, r in enumerate(rows) for s0 in range(0, r[5], ce)]
+                cc = (_OptChunk * len(chunks))(*[_OptChunk(*c) for c in chunks])
+                tdev = torch.frombuffer(bytearray(bytes(tt)), dtype=torch.uint8).to(dev)
+                cdev = torch.frombuffer(bytearray(bytes(cc)), dtype=torch.uint8).to(dev)
+                self._tables = (key, tdev, cdev, len(chunks))
+                self._scratch = torch.zeros((1,), dtype=torch.float64, device=dev)
+            _, tdev, cdev, nchunks = self._tables
+            t = int(self.state[ps[0]]["step"].item()) + 1
+            b1, b2 = group["betas"]
+            rc = lib.ctdd_adam_ema_step(tdev.data_ptr(), cdev.data_ptr(), nchunks, float(group["lr"]), float(b1), float(b2),
+                                        float(group["eps"]), t, float(max_norm), float(ema_decay if shadow_params is not None else -1.0),
+                                        self._scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise native.CtddError(f"ctdd_adam_ema_step failed ({rc}): {lib.ctdd_last_error().decode()}")
+            for p in ps:
+                self.state[p]["step"] += 1
+
+
 @optimizers_utils.register_optimizer
 def Adam(params, cfg):
-    return torch.optim.Adam(params, cfg.optimizer.lr)
+    return FusedAdam(params, cfg.optimizer.lr)

@@ -37,12 +37,24 @@ class Standard:
             print("Loss is nan or inf")
             return torch.tensor(1e9, device=self.device)
         l.backward()
-        if self.clip_grad:
-            torch.nn.utils.clip_grad_norm_(state["model"].parameters(), self.grad_norm)
-        if self.warmup > 0:
-            for g in state["optimizer"].param_groups:
+        opt, model = state["optimizer"], state["model"]
+        if self.warmup > 0:                                   # (the reference sets the LR after clipping; the two commute)
+            for g in opt.param_groups:
                 g["lr"] = self.lr * np.minimum(state["n_iter"] / self.warmup, 1.0)
-        state["optimizer"].step()
-        if self.do_ema:
-            state["model"].update_ema()
+        owner = model.module if hasattr(model, "module") else model      # DDP wrapper
+        first = next(model.parameters())
+        if first.is_cuda and hasattr(opt, "fused_step"):
+            # K28: clip + Adam + EMA of every tensor in two libctdd launches (csrc/optim.hip)
+            shadow, decay, trainable = None, -1.0, None
+            if self.do_ema:
+                decay = owner.next_ema_decay()
+                shadow, trainable = owner.shadow_params, owner._trainable()
+            opt.fused_step(self.grad_norm if self.clip_grad else 0.0, shadow, decay, trainable)
+            owner._weights_version = getattr(owner, "_weights_version", 0) + 1    # raw-pointer writes: tell the inference engine
+        else:                                                  # host-logic path for cfg.device == "cpu" (torch ops, as the reference)
+            if self.clip_grad:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), self.grad_norm)
+            opt.step()
+            if self.do_ema:
+                model.update_ema()
         return l.detach()

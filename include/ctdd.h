@@ -164,6 +164,18 @@ int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, const int32_t*
 int ctdd_philox_uniform(uint64_t seed, uint64_t offset, int64_t nrows, int nblk, float* out,
                         void* stream);
 
+/* ---- K28: clip_grad_norm_ + Adam.step + EMA update over all parameter tensors in two launches
+ * (lib/training/training.py:17-40, lib/models/models.py:745-758, torch.optim.Adam single-tensor formulas).
+ * tensors: device array of ctdd_opt_tensor; chunks: device array of ctdd_opt_chunk covering every tensor in
+ * pieces of ctdd_opt_chunk_elems() elements.  max_norm <= 0: no clipping; ema_decay < 0: no EMA; a null
+ * shadow pointer skips the EMA of that tensor.  Gradients are read, not rescaled in place. */
+typedef struct { float* p; const float* g; float* m; float* v; float* shadow; int64_t n; } ctdd_opt_tensor;
+typedef struct { int tensor; int pad; int64_t start; } ctdd_opt_chunk;
+int ctdd_opt_chunk_elems(void);
+int ctdd_adam_ema_step(const void* tensors, const void* chunks, int nchunks, float lr, float beta1, float beta2,
+                       float eps, int64_t step, float max_norm, float ema_decay, double* sumsq_scratch,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
