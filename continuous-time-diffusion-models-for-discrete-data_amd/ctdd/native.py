@@ -47,6 +47,7 @@ _SIGS = {
     "ctdd_s256_step_table_bytes": ([], _I64),
     "ctdd_s256_prepare": ([_P, _P, _F, _I, _P, _P, _P, _P], _I),
     "ctdd_tauleap_step_s256": ([_P, _P, _P, _P, _P, _P, _F, _F, _U32, _U64, _U64, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_crm_loss": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_opt_chunk_elems": ([], _I),
     "ctdd_adam_ema_step": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
 }
@@ -233,6 +234,20 @@ def philox_uniform(seed, offset, nrows, nblk, device):
     out = torch.empty((nrows, nblk * 4), dtype=f32, device=device)
     _check(load().ctdd_philox_uniform(seed, offset, nrows, nblk, _ptr(out), _stream()), "ctdd_philox_uniform")
     return out
+
+
+def crm_loss(logits, xt, x0, qt0, loss_type, scale, nll_scale):
+    """K12: (loss scalar tensor, d loss / d logits) for the CRM objectives with direct logits."""
+    B, D, S = logits.shape
+    grad = torch.empty_like(logits)
+    rows = torch.empty((B * D,), dtype=torch.float64, device=logits.device)
+    out = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    lt = {"rm": 0, "mle": 1, "elbo": 2}[loss_type]
+    _check(load().ctdd_crm_loss(_ptr(logits, torch.float32, "logits"), _ptr(xt, torch.int32, "xt"),
+                                _ptr(x0, torch.int32, "x0") if x0 is not None else None,
+                                _ptr(qt0, torch.float32, "qt0") if qt0 is not None else None, B, D, S, lt, float(scale),
+                                float(nll_scale), _ptr(grad), _ptr(rows), _ptr(out), _stream()), "ctdd_crm_loss")
+    return out[0], grad
 
 
 # ---------------------------------------------------------------- S = 256 fast path

@@ -167,6 +167,38 @@ def _crm_loss(cfg, model, xt, t, ll_all, ll_xt):
     raise ValueError("Unknown loss_type: %s" % lt)
 
 
+class _CrmLossFn(torch.autograd.Function):
+    """K12 (csrc/losses.hip): value and logit-gradient of the CRM objective in one HIP pass."""
+
+    @staticmethod
+    def forward(ctx, logits, xt, x0, qt0, loss_type, scale, nll_scale):
+        val, grad = native.crm_loss(logits.detach().float().contiguous(), xt.to(torch.int32).contiguous(),
+                                    None if x0 is None else x0.to(torch.int32).contiguous(),
+                                    None if qt0 is None else qt0.float().contiguous(), loss_type, scale, nll_scale)
+        ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None
+
+
+def _crm_objective(cfg, model, logits, xt, ts, x0, nll_weight):
+    """sum(loss_bd) (1 - ce_coeff) / B [+ nll_weight * CE(logits, x0)]; direct logits on a GPU run in K12."""
+    B, D = xt.shape
+    scale = (1.0 - cfg.loss.ce_coeff) / B
+    if cfg.loss.logit_type == "direct" and logits.is_cuda:
+        qt0 = model.transition(ts) if cfg.loss.loss_type == "elbo" else None
+        return _CrmLossFn.apply(logits, xt, x0 if nll_weight else None, qt0, cfg.loss.loss_type, scale,
+                                float(nll_weight) / (B * D) if nll_weight else 0.0)
+    ll_all, ll_xt = get_logprob_with_logits(cfg, model, xt, ts, logits)      # reverse_prob / reverse_logscale: device ops
+    out = torch.sum(_crm_loss(cfg, model, xt, ts, ll_all, ll_xt)) * scale
+    if nll_weight:
+        out = out + nll_weight * F.cross_entropy(logits.permute(0, 2, 1), x0)
+    return out
+
+
 class _CRMBase:
     clamp_t = True
     t_hi = 1.0
@@ -195,9 +227,7 @@ class CatRM(_CRMBase):
         state, minibatch = _unpack(state, minibatch)
         model, x0, ts, xt = self._forward(state, minibatch)
         logits = model(xt, ts)
-        ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, xt, ts, logits)
-        loss = _crm_loss(self.cfg, model, xt, ts, ll_all, ll_xt) * (1 - self.cfg.loss.ce_coeff)
-        return torch.sum(loss) / x0.shape[0]
+        return _crm_objective(self.cfg, model, logits, xt, ts, None, 0.0)
 
 
 @losses_utils.register_loss
@@ -215,10 +245,7 @@ class CatRMNLL(_CRMBase):
         state, minibatch = _unpack(minibatch, state)
         model, x0, ts, xt = self._forward(state, minibatch)
         logits = model(xt, ts)
-        ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, xt, ts, logits)
-        loss = _crm_loss(self.cfg, model, xt, ts, ll_all, ll_xt) * (1 - self.cfg.loss.ce_coeff)
-        nll = self.cross_ent(logits.permute(0, 2, 1), x0)
-        return torch.sum(loss) / x0.shape[0] + self.nll_weight * nll
+        return _crm_objective(self.cfg, model, logits, xt, ts, x0, self.nll_weight)
 
 
 @losses_utils.register_loss

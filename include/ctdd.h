@@ -164,6 +164,15 @@ int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, const int32_t*
 int ctdd_philox_uniform(uint64_t seed, uint64_t offset, int64_t nrows, int nblk, float* out,
                         void* stream);
 
+/* ---- K12: categorical ratio matching objectives with the 'direct' logit type, value and d/dlogits in one pass
+ * (lib/losses/losses.py: CatRM._comp_loss 794-836, CatRM.calc_loss 838-890, CatRMNLL 1146-1242;
+ * model_utils.py:30-38).  loss_type 0 'rm', 1 'mle', 2 'elbo' (needs qt0 (B,S,S)).
+ * out_loss = scale * sum_{b,d} loss_bd + nll_scale * sum_{b,d} -log_softmax(logits)[x0]   (x0 null: no CE term)
+ * grad_logits (B,D,S) = d out_loss / d logits.  row_scratch: B*D doubles. */
+int ctdd_crm_loss(const float* logits, const int32_t* xt, const int32_t* x0, const float* qt0, int B, int D, int S,
+                  int loss_type, float scale, float nll_scale, float* grad_logits, double* row_scratch,
+                  float* out_loss, void* stream);
+
 /* ---- K28: clip_grad_norm_ + Adam.step + EMA update over all parameter tensors in two launches
  * (lib/training/training.py:17-40, lib/models/models.py:745-758, torch.optim.Adam single-tensor formulas).
  * tensors: device array of ctdd_opt_tensor; chunks: device array of ctdd_opt_chunk covering every tensor in
