@@ -143,3 +143,292 @@ extern "C" int ctdd_crm_loss(const float* logits, const int32_t* xt, const int32
   hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, st, (const double*)row_scratch, a.rows, out_loss);
   return finish_launch("k_sum_rows");
 }
+
+// ================================================================== K11: tauLDR CT-ELBO, value + d/dlogits
+// Reference lib/losses/losses.py:106-286 (CTElbo.calc_loss; NLL / CTElboLambda share the body) with
+// one_forward_pass = True: logits = model(x_t), reg_x = x~.  Per sample b with tables q = q_{t|0}
+// (B,S,S), qT = its transpose, R = rate(t), and per row (b,d) with x = x~_bd, p = softmax(l):
+//   reg_row   = sum_s0 p[s0] A[x][s0],     A[x][s0] = (sum_{s != x} R[s,x] q[s0,s]) / (q[s0,x] + eps)
+//   u[s]      = sum_s0 (p[s0] / (q[s0,x] + eps)) q[s0,s],   inner = log(u + eps)
+//   Wt[s]     = [s != x] R[s,x] q[x0,s] / (q[x0,x] + eps)
+//   outer_row = sum_s Wt[s] inner[s]
+//   norm_row  = sum_s [s != x] R[s,x] q[x0,s] / (Z[s] (q[x0,x] + eps)),  Z[s] = sum_d' rs[x~_bd'] - rs[x] + rs[s], rs = -diag R
+//   loss = elbo_scale * ( mean_b( -sum_d outer / sum_d norm ) + mean_b sum_d reg ) + nll_scale * sum_{b,d} -log p[x0]
+// Backward: G[s] = c_b Wt[s] / (u[s] + eps), c_b = -elbo_scale / (B norm_b);  dr[s0] = sum_s G[s] q[s0,s];
+//   dp[s0] = dr[s0] / (q[s0,x] + eps) + (elbo_scale / B) A[x][s0];  dl[j] = p[j] (dp[j] - sum p dp) + nll_scale (p[j] - [j = x0]).
+// Workgroup = 8 rows of one sample, thread s <-> state s (S <= 256); the two S x S contractions stream q / qT
+// once per 8 rows with the row vectors in LDS.  Correctness-first (fp32 FMA chains, no matrix cores yet).
+namespace ctdd {
+
+constexpr int LRB = 8;   // rows per workgroup
+
+struct ElboArgs {
+  const float* logits; const int32_t* x0; const int32_t* xt;     // xt = x~ (= reg_x)
+  const float* q; const float* qT; const float* R;               // (B,S,S) each
+  int B, D, S; float eps, elbo_scale, nll_scale;
+  float* Atab;        // (B,S,S): A[b][x][s0]
+  float* base_sum;    // (B)
+  float* u;           // (B,D,S)
+  double* rows;       // (B*D,4): outer, norm, reg, nll
+  float* cb;          // (B)
+  float* grad;        // (B,D,S)
+  float* out_loss;    // (1)
+};
+
+// block reduction of LRB values per thread; result broadcast through red[]
+__device__ inline void block_sum8(float (&v)[LRB], float* red /* [4][LRB] */, float (&out)[LRB]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const float s = lwave_sum(v[r]);
+    if (lane == 0) red[w * LRB + r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) out[r] = (red[r] + red[LRB + r]) + (red[2 * LRB + r] + red[3 * LRB + r]);
+  __syncthreads();
+}
+__device__ inline void block_max8(float (&v)[LRB], float* red, float (&out)[LRB]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const float s = lwave_max(v[r]);
+    if (lane == 0) red[w * LRB + r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) out[r] = fmaxf(fmaxf(red[r], red[LRB + r]), fmaxf(red[2 * LRB + r], red[3 * LRB + r]));
+  __syncthreads();
+}
+
+// A table + base_sum.  grid (ceil(S/LRB), B): rows s0 of sample b.
+__global__ __launch_bounds__(256) void k_elbo_atab(const ElboArgs a) {
+  __shared__ float qrow[LRB][256];
+  const int S = a.S, b = blockIdx.y, s00 = blockIdx.x * LRB, t = threadIdx.x;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* R = a.R + (size_t)b * S * S;
+  for (int i = t; i < LRB * S; i += 256) {
+    const int r = i / S, s = i % S;
+    qrow[r][s] = s00 + r < S ? q[(size_t)(s00 + r) * S + s] : 0.0f;
+  }
+  __syncthreads();
+  if (t < S) {                                      // thread = x
+    float acc[LRB];
+#pragma unroll
+    for (int r = 0; r < LRB; ++r) acc[r] = 0.0f;
+    for (int s = 0; s < S; ++s) {
+      const float rv = s == t ? 0.0f : R[(size_t)s * S + t];
+#pragma unroll
+      for (int r = 0; r < LRB; ++r) acc[r] = fmaf(qrow[r][s], rv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < LRB; ++r)
+      if (s00 + r < S) a.Atab[((size_t)b * S + t) * S + s00 + r] = acc[r] / (qrow[r][t] + a.eps);
+  }
+  if (blockIdx.x == 0) {                            // base_sum[b] = sum_d rs[x~_bd]
+    float s = 0.0f;
+    for (int d = t; d < a.D; d += 256) {
+      const int x = min(max(a.xt[(size_t)b * a.D + d], 0), S - 1);
+      s -= R[(size_t)x * S + x];
+    }
+    __shared__ float red[4];
+    s = lwave_sum(s);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) a.base_sum[b] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// forward rows.  grid (ceil(D/LRB), B)
+__global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
+  __shared__ float rvec[LRB][256];
+  __shared__ float red[4 * LRB];
+  const int S = a.S, D = a.D, b = blockIdx.y, d0 = blockIdx.x * LRB, t = threadIdx.x;
+  const bool act = t < S;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* qT = a.qT + (size_t)b * S * S;
+  const float* R = a.R + (size_t)b * S * S;
+  int x[LRB], x0[LRB];
+  bool ok[LRB];
+  float l[LRB], mx[LRB], tmp[LRB], p[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    ok[r] = d0 + r < D;
+    const size_t row = (size_t)b * D + (ok[r] ? d0 + r : D - 1);
+    x[r] = min(max(a.xt[row], 0), S - 1);
+    x0[r] = min(max(a.x0[row], 0), S - 1);
+    l[r] = act ? a.logits[row * S + t] : -INFINITY;
+    tmp[r] = l[r];
+  }
+  block_max8(tmp, red, mx);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) tmp[r] = act ? expf(l[r] - mx[r]) : 0.0f;
+  float zs[LRB];
+  block_sum8(tmp, red, zs);
+  float regp[LRB], nllp[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const float L = mx[r] + logf(zs[r]);
+    p[r] = act ? expf(l[r] - L) : 0.0f;
+    const float den = act ? qT[(size_t)x[r] * S + t] + a.eps : 1.0f;
+    rvec[r][t] = p[r] / den;
+    regp[r] = act ? p[r] * a.Atab[((size_t)b * S + x[r]) * S + t] : 0.0f;
+    nllp[r] = (act && t == x0[r]) ? -(l[r] - L) : 0.0f;
+  }
+  __syncthreads();
+  float acc[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) acc[r] = 0.0f;
+  if (act)
+    for (int s0 = 0; s0 < S; ++s0) {
+      const float qv = q[(size_t)s0 * S + t];
+#pragma unroll
+      for (int r = 0; r < LRB; ++r) acc[r] = fmaf(rvec[r][s0], qv, acc[r]);
+    }
+  const float bsum = a.base_sum[b];
+  float outp[LRB], normp[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    outp[r] = 0.0f; normp[r] = 0.0f;
+    if (act) {
+      const size_t row = (size_t)b * D + d0 + r;
+      if (ok[r]) a.u[row * S + t] = acc[r];
+      const float orate = t == x[r] ? 0.0f : R[(size_t)t * S + x[r]];
+      const float qx0 = q[(size_t)x0[r] * S + t];
+      const float qx0xt = q[(size_t)x0[r] * S + x[r]] + a.eps;
+      const float Z = bsum + R[(size_t)x[r] * S + x[r]] - R[(size_t)t * S + t];      // base_sum - rs[x] + rs[s]
+      outp[r] = orate * (qx0 / qx0xt) * logf(acc[r] + a.eps);
+      normp[r] = orate * qx0 / (Z * qx0xt);
+    }
+  }
+  float o1[LRB], o2[LRB], o3[LRB], o4[LRB];
+  block_sum8(outp, red, o1);
+  block_sum8(normp, red, o2);
+  block_sum8(regp, red, o3);
+  block_sum8(nllp, red, o4);
+  if (t < LRB && d0 + t < D) {
+    double* dst = a.rows + ((size_t)b * D + d0 + t) * 4;
+    float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+#pragma unroll
+    for (int r = 0; r < LRB; ++r)
+      if (r == t) { v1 = o1[r]; v2 = o2[r]; v3 = o3[r]; v4 = o4[r]; }
+    dst[0] = v1; dst[1] = v2; dst[2] = v3; dst[3] = v4;
+  }
+}
+
+// per-sample sums -> c_b and the scalar loss.  one workgroup.
+__global__ __launch_bounds__(256) void k_elbo_reduce(const ElboArgs a) {
+  __shared__ double acc[256];
+  double tot = 0.0;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    double so = 0.0, sn = 0.0, sr = 0.0, sl = 0.0;
+    for (int d = 0; d < a.D; ++d) {
+      const double* r = a.rows + ((size_t)b * a.D + d) * 4;
+      so += r[0]; sn += r[1]; sr += r[2]; sl += r[3];
+    }
+    a.cb[b] = (float)(-(double)a.elbo_scale / ((double)a.B * sn));
+    tot += (double)a.elbo_scale * ((-so / sn) + sr) / (double)a.B + (double)a.nll_scale * sl;
+  }
+  acc[threadIdx.x] = tot;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) acc[threadIdx.x] += acc[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.out_loss[0] = (float)acc[0];
+}
+
+// backward rows.  grid (ceil(D/LRB), B)
+__global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
+  __shared__ float gvec[LRB][256];
+  __shared__ float red[4 * LRB];
+  const int S = a.S, D = a.D, b = blockIdx.y, d0 = blockIdx.x * LRB, t = threadIdx.x;
+  const bool act = t < S;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* qT = a.qT + (size_t)b * S * S;
+  const float* R = a.R + (size_t)b * S * S;
+  const float cb = a.cb[b];
+  int x[LRB], x0[LRB];
+  bool ok[LRB];
+  float l[LRB], mx[LRB], tmp[LRB], p[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    ok[r] = d0 + r < D;
+    const size_t row = (size_t)b * D + (ok[r] ? d0 + r : D - 1);
+    x[r] = min(max(a.xt[row], 0), S - 1);
+    x0[r] = min(max(a.x0[row], 0), S - 1);
+    l[r] = act ? a.logits[row * S + t] : -INFINITY;
+    tmp[r] = l[r];
+    // G[s] = c_b Wt[s] / (u[s] + eps)
+    float G = 0.0f;
+    if (act) {
+      const float orate = t == x[r] ? 0.0f : R[(size_t)t * S + x[r]];
+      const float qx0 = q[(size_t)x0[r] * S + t];
+      const float qx0xt = q[(size_t)x0[r] * S + x[r]] + a.eps;
+      G = cb * orate * (qx0 / qx0xt) / (a.u[row * S + t] + a.eps);
+    }
+    gvec[r][t] = G;
+  }
+  block_max8(tmp, red, mx);                          // (contains the barrier that publishes gvec)
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) tmp[r] = act ? expf(l[r] - mx[r]) : 0.0f;
+  float zs[LRB];
+  block_sum8(tmp, red, zs);
+  float acc[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) { acc[r] = 0.0f; p[r] = act ? expf(l[r] - (mx[r] + logf(zs[r]))) : 0.0f; }
+  if (act)
+    for (int s = 0; s < S; ++s) {                    // dr[s0 = t] = sum_s G[s] q[s0, s] = sum_s G[s] qT[s, s0]
+      const float qv = qT[(size_t)s * S + t];
+#pragma unroll
+      for (int r = 0; r < LRB; ++r) acc[r] = fmaf(gvec[r][s], qv, acc[r]);
+    }
+  float dp[LRB], pd[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    dp[r] = 0.0f;
+    if (act) dp[r] = acc[r] / (qT[(size_t)x[r] * S + t] + a.eps) + (a.elbo_scale / (float)a.B) * a.Atab[((size_t)b * S + x[r]) * S + t];
+    pd[r] = p[r] * dp[r];
+  }
+  float pdot[LRB];
+  block_sum8(pd, red, pdot);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r)
+    if (act && ok[r])
+      a.grad[((size_t)b * D + d0 + r) * S + t] = p[r] * (dp[r] - pdot[r]) + a.nll_scale * (p[r] - (t == x0[r] ? 1.0f : 0.0f));
+}
+
+}  // namespace ctdd
+
+extern "C" int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S) {
+  // Atab (B,S,S) f32 | u (B,D,S) f32 | rows (B*D,4) f64 | base_sum (B) f32 | cb (B) f32   (each 256-B aligned)
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  return al((int64_t)B * S * S * 4) + al((int64_t)B * D * S * 4) + al((int64_t)B * D * 32) + 2 * al((int64_t)B * 4);
+}
+
+extern "C" int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
+                                const float* rate, int B, int D, int S, float eps, float elbo_scale, float nll_scale,
+                                void* scratch, float* grad_logits, float* out_loss, void* stream) {
+  CTDD_REQUIRE(logits && x0 && x_tilde && qt0 && qt0T && rate && scratch && grad_logits && out_loss, CTDD_EINVAL, "ct-elbo: null buffer");
+  CTDD_REQUIRE(B > 0 && D > 0 && S >= 2 && S <= 256, CTDD_ERANGE, "ct-elbo: B=%d D=%d S=%d (S <= 256)", B, D, S);
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  unsigned char* sp = (unsigned char*)scratch;
+  ElboArgs a;
+  a.logits = logits; a.x0 = x0; a.xt = x_tilde; a.q = qt0; a.qT = qt0T; a.R = rate;
+  a.B = B; a.D = D; a.S = S; a.eps = eps; a.elbo_scale = elbo_scale; a.nll_scale = nll_scale;
+  a.Atab = (float*)sp; sp += al((int64_t)B * S * S * 4);
+  a.u = (float*)sp; sp += al((int64_t)B * D * S * 4);
+  a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
+  a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
+  a.cb = (float*)sp;
+  a.grad = grad_logits; a.out_loss = out_loss;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_elbo_atab, dim3((S + LRB - 1) / LRB, B), dim3(256), 0, st, a);
+  if (int rc = finish_launch("k_elbo_atab")) return rc;
+  hipLaunchKernelGGL(k_elbo_fwd, dim3((D + LRB - 1) / LRB, B), dim3(256), 0, st, a);
+  if (int rc = finish_launch("k_elbo_fwd")) return rc;
+  hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a);
+  if (int rc = finish_launch("k_elbo_reduce")) return rc;
+  hipLaunchKernelGGL(k_elbo_bwd, dim3((D + LRB - 1) / LRB, B), dim3(256), 0, st, a);
+  return finish_launch("k_elbo_bwd");
+}

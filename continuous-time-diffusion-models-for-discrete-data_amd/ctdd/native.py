@@ -48,6 +48,8 @@ _SIGS = {
     "ctdd_s256_prepare": ([_P, _P, _F, _I, _P, _P, _P, _P], _I),
     "ctdd_tauleap_step_s256": ([_P, _P, _P, _P, _P, _P, _F, _F, _U32, _U64, _U64, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_crm_loss": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
+    "ctdd_ctelbo_scratch_bytes": ([_I, _I, _I], _I64),
+    "ctdd_ctelbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_opt_chunk_elems": ([], _I),
     "ctdd_adam_ema_step": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
 }
@@ -247,6 +249,20 @@ def crm_loss(logits, xt, x0, qt0, loss_type, scale, nll_scale):
                                 _ptr(x0, torch.int32, "x0") if x0 is not None else None,
                                 _ptr(qt0, torch.float32, "qt0") if qt0 is not None else None, B, D, S, lt, float(scale),
                                 float(nll_scale), _ptr(grad), _ptr(rows), _ptr(out), _stream()), "ctdd_crm_loss")
+    return out[0], grad
+
+
+def ctelbo_loss(logits, x0, x_tilde, qt0, qt0T, rate, eps, elbo_scale, nll_scale):
+    """K11: (loss scalar tensor, d loss / d logits) of the tauLDR CT-ELBO (one forward pass)."""
+    B, D, S = logits.shape
+    lib = load()
+    scratch = torch.empty((int(lib.ctdd_ctelbo_scratch_bytes(B, D, S)),), dtype=torch.uint8, device=logits.device)
+    grad = torch.empty_like(logits)
+    out = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    _check(lib.ctdd_ctelbo_loss(_ptr(logits, torch.float32, "logits"), _ptr(x0, torch.int32, "x0"), _ptr(x_tilde, torch.int32, "x_tilde"),
+                                _ptr(qt0, torch.float32, "qt0"), _ptr(qt0T, torch.float32, "qt0T"), _ptr(rate, torch.float32, "rate"),
+                                B, D, S, float(eps), float(elbo_scale), float(nll_scale), _ptr(scratch), _ptr(grad), _ptr(out),
+                                _stream()), "ctdd_ctelbo_loss")
     return out[0], grad
 
 

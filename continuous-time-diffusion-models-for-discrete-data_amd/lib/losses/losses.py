@@ -47,20 +47,40 @@ def _draw_ts(B, device, lo, hi):
     return torch.rand((B,), device=device) * (hi - lo) + lo
 
 
-def _noise(model, x0, ts, with_tilde):
+def _noise(model, x0, ts, with_tilde, want_T=False):
     """x_t ~ q_{t|0}(.|x0) per dimension and optionally the one-jump neighbour x~ (losses.py:39-101).
-    Returns qt0, rate (B,S,S) and int64 x_t[, x~]."""
+    Returns qt0, rate (B,S,S) and int64 x_t[, x~]; with want_T the transposed table q_{t|0}^T is appended."""
     if _FIXED_NOISE is not None:
-        qt0, _, rate, _ = model.process.tables(ts, want_qt0=True, want_rate=True)
+        qt0, qT, rate, _ = model.process.tables(ts, want_qt0=True, want_qt0T=want_T, want_rate=True)
         xt = _FIXED_NOISE["x_t"].to(x0.device).long()
-        return qt0, rate, xt, (_FIXED_NOISE["x_tilde"].to(x0.device).long() if with_tilde else None)
-    qt0, _, rate, probs = model.process.tables(ts, want_qt0=True, want_rate=True, want_noise_probs=True)
+        out = (qt0, rate, xt, (_FIXED_NOISE["x_tilde"].to(x0.device).long() if with_tilde else None))
+        return out + (qT,) if want_T else out
+    qt0, qT, rate, probs = model.process.tables(ts, want_qt0=True, want_qt0T=want_T, want_rate=True, want_noise_probs=True)
     x0i = x0.to(torch.int32).contiguous()
     x_t = native.noise_categorical(probs, x0i, seed=_seed())
     if not with_tilde:
-        return qt0, rate, x_t.long(), None
+        out = (qt0, rate, x_t.long(), None)
+        return out + (qT,) if want_T else out
     _, _, x_tilde = native.xtilde_sample(rate, x_t, seed=_seed())
-    return qt0, rate, x_t.long(), x_tilde.long()
+    out = (qt0, rate, x_t.long(), x_tilde.long())
+    return out + (qT,) if want_T else out
+
+
+class _CtElboFn(torch.autograd.Function):
+    """K11 (csrc/losses.hip): CT-ELBO value and logit-gradient in HIP (one forward pass)."""
+
+    @staticmethod
+    def forward(ctx, logits, x0, x_tilde, qt0, qt0T, rate, eps, elbo_scale, nll_scale):
+        val, grad = native.ctelbo_loss(logits.detach().float().contiguous(), x0.to(torch.int32).contiguous(),
+                                       x_tilde.to(torch.int32).contiguous(), qt0.contiguous(), qt0T.contiguous(),
+                                       rate.contiguous(), eps, elbo_scale, nll_scale)
+        ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g,) + (None,) * 8
 
 
 def _masked_rows(tab, x):
@@ -100,28 +120,32 @@ class _CTElboBase:
         self.max_t = cfg.training.max_t
         self.cross_ent = nn.CrossEntropyLoss()
 
-    def _pieces(self, state, minibatch):
+    def _total(self, state, minibatch, elbo_scale, nll_coef):
+        """elbo_scale * neg_elbo + nll_coef * CE(logits, x0).  With one forward pass on a GPU the objective and
+        its logit gradient run in K11 (csrc/losses.hip); two forward passes keep the differentiable device ops."""
         model = state["model"]
         x0 = _flatten(minibatch).long()
-        B = x0.shape[0]
+        B, D = x0.shape
         ts = _draw_ts(B, model.device, self.min_time, self.max_t)
-        qt0, rate, x_t, x_tilde = _noise(model, x0, ts, True)
+        qt0, rate, x_t, x_tilde, qT = _noise(model, x0, ts, True, want_T=True)
         x_logits = model(x_t, ts)
+        if self.one_forward_pass and x_logits.is_cuda and x_logits.shape[-1] <= 256 and getattr(self.cfg.loss, "fused", True):
+            return _CtElboFn.apply(x_logits, x0, x_tilde, qt0, qT, rate, float(self.ratio_eps), float(elbo_scale),
+                                   float(nll_coef) / (B * D))
         if self.one_forward_pass:
             logits_sig, reg_x = x_logits, x_tilde
         else:
             logits_sig, reg_x = model(x_tilde, ts), x_t
         neg_elbo = _ct_elbo_terms(x_logits, logits_sig, x0, reg_x, x_tilde, qt0, rate, self.ratio_eps)
         nll = self.cross_ent(x_logits.permute(0, 2, 1), x0)
-        return neg_elbo, nll
+        return elbo_scale * neg_elbo + nll_coef * nll
 
 
 @losses_utils.register_loss
 class CTElbo(_CTElboBase):
     def calc_loss(self, state, minibatch, label=None):
         state, minibatch = _unpack(state, minibatch)
-        neg_elbo, nll = self._pieces(state, minibatch)
-        return neg_elbo + self.nll_weight * nll
+        return self._total(state, minibatch, 1.0, self.nll_weight)
 
 
 @losses_utils.register_loss
@@ -130,7 +154,7 @@ class NLL(_CTElboBase):
 
     def calc_loss(self, state, minibatch, label=None):
         state, minibatch = _unpack(state, minibatch)
-        return self._pieces(state, minibatch)[1]
+        return self._total(state, minibatch, 0.0, 1.0)
 
 
 @losses_utils.register_loss
@@ -144,8 +168,7 @@ class CTElboLambda(_CTElboBase):
     def calc_loss(self, state, minibatch, label=None):
         state, minibatch = _unpack(state, minibatch)
         w = state["n_iter"] / self.max_iter
-        neg_elbo, nll = self._pieces(state, minibatch)
-        return w * neg_elbo + (1 - w) * nll
+        return self._total(state, minibatch, w, 1 - w)
 
 
 def _crm_loss(cfg, model, xt, t, ll_all, ll_xt):

@@ -173,6 +173,16 @@ int ctdd_crm_loss(const float* logits, const int32_t* xt, const int32_t* x0, con
                   int loss_type, float scale, float nll_scale, float* grad_logits, double* row_scratch,
                   float* out_loss, void* stream);
 
+/* ---- K11: tauLDR CT-ELBO with one_forward_pass (logits = model(x_t), reg_x = x~), value and d/dlogits
+ * (lib/losses/losses.py:106-286; NLL 1598-1778 and CTElboLambda 1879-2058 share the body).
+ * out_loss = elbo_scale * (mean_b(-sig_b / norm_b) + mean_b(reg_b)) + nll_scale * sum_{b,d} -log_softmax(logits)[x0]
+ * (CTElbo: elbo_scale 1, nll_scale nll_weight/(B*D); CTElboLambda: w and (1-w)/(B*D)).  qt0, qt0T, rate: (B,S,S) per-sample
+ * tables (K1); S <= 256.  scratch: ctdd_ctelbo_scratch_bytes(B,D,S) bytes. */
+int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S);
+int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
+                     const float* rate, int B, int D, int S, float eps, float elbo_scale, float nll_scale,
+                     void* scratch, float* grad_logits, float* out_loss, void* stream);
+
 /* ---- K28: clip_grad_norm_ + Adam.step + EMA update over all parameter tensors in two launches
  * (lib/training/training.py:17-40, lib/models/models.py:745-758, torch.optim.Adam single-tensor formulas).
  * tensors: device array of ctdd_opt_tensor; chunks: device array of ctdd_opt_chunk covering every tensor in

@@ -113,3 +113,27 @@ def test_hip_noising_inside_loss(golden, tag):
     a, b = np.array(vals), np.array(ovals)
     se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b)) + 1e-9
     assert abs(a.mean() - b.mean()) < 6 * se + 0.02 * abs(b.mean()), (a, b)
+
+
+@pytest.mark.parametrize("S,D", [(3, 15), (256, 37), (100, 8)])
+@pytest.mark.parametrize("loss_type", ["rm", "mle", "elbo"])
+def test_crm_kernel_matches_oracle_formulas(S, D, loss_type):
+    """K12 (ctdd_crm_loss) against the oracle's CRM objective + CE on random logits: value and d/dlogits."""
+    from ctdd import native
+    from oracle import losses as ol, ctmc_ops as ops
+    import torch.nn.functional as F
+    B = 3
+    g = torch.Generator().manual_seed(S + D)
+    logits = torch.randn(B, D, S, generator=g) * 2.0
+    xt = torch.randint(0, S, (B, D), generator=g)
+    x0 = torch.randint(0, S, (B, D), generator=g)
+    qt0 = torch.softmax(torch.randn(B, S, S, generator=g), -1)
+    scale, nllw = 0.7 / B, 0.05
+    lo = logits.clone().requires_grad_(True)
+    ll_all, ll_xt = ops.logprob_with_logits("direct", lo, xt, qt0)
+    want = torch.sum(ol.crm_comp_loss(loss_type, S, ll_all, ll_xt, xt, qt0)) * scale + nllw * F.cross_entropy(lo.permute(0, 2, 1), x0)
+    wgrad, = torch.autograd.grad(want, lo)
+    val, grad = native.crm_loss(logits.cuda(), xt.to(torch.int32).cuda(), x0.to(torch.int32).cuda(), qt0.cuda(), loss_type, scale,
+                                nllw / (B * D))
+    np.testing.assert_allclose(val.item(), want.item(), rtol=2e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), wgrad.numpy(), rtol=2e-4, atol=2e-6)
