@@ -84,10 +84,16 @@ def kernel_roofline(sampler, st, steps, batch):
         e1.synchronize()
         times.append(e0.elapsed_time(e1) * 1e-3)
     dur = float(np.mean(times))
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_tauleap_s256.json")
+    if batch == 256 and os.path.exists(pmc):          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload)
+        with open(pmc) as f:
+            rec = json.load(f)
+        traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic_tauleap_s256.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
     achieved = ALGO_BYTES_PER_SAMPLE_STEP * batch / dur / 1e9
     mfma_flops = 3 * 2 * D * S * S * batch                     # hi*hi + hi*lo + lo*hi products of the S x S contraction
     return {"kernel": "ctdd k_tauleap_s256 (fused softmax + split-bf16 MFMA contraction + Poisson draw + update)", "bound": "hbm", "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch,
             "mfma_view": {"achieved": round(mfma_flops / dur / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(mfma_flops / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
