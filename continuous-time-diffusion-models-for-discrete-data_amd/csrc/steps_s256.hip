@@ -446,11 +446,15 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
   }
   return;
 #endif
+  bool moved = false;
   if (live && g == 0) {
     const int xn = min(max(xcur + jump, 0), S256 - 1);
     a.out_x[myrow] = xn;
-    const bool moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
-    if (a.out_changed && moved) atomicAdd(a.out_changed, 1);
+    moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
+  }
+  if (a.out_changed) {                       // one atomic per wave instead of one per row on a single address
+    const int nmoved = __builtin_popcountll(__ballot(moved));
+    if (lane == 0 && nmoved) atomicAdd(a.out_changed, nmoved);
   }
 }
 
