@@ -62,6 +62,7 @@ struct ConvArgs {
   int logits_C;               // > 0: out_f32 is (B, logits_C*H*W, N/logits_C): row = c*HW + p
   int ksplit;                 // > 1: grid.z workgroups each take a share of K and add into acc_buf
   float* acc_buf;             // [M][N] fp32, zeroed by the caller; finished by k_conv_finish
+  int act;                    // generic kernel only: 0 none, 1 ReLU, 2 GELU (erf), applied to acc + bias before the residual
 };
 
 constexpr int BM = 128;
@@ -128,6 +129,8 @@ __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, 
     if (p < M && ncol) {
       const bool second = p >= next_sample;
       float v = acc[r] + bv + (second ? tb1 : tb0);
+      if (a.act == 1) v = fmaxf(v, 0.0f);
+      else if (a.act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
       const size_t o = (size_t)p * a.N + n;
       if (a.res_f32) v += a.res_f32[o];
       else if (a.res_bf16) v += from_bf16(a.res_bf16[o]);

@@ -1,0 +1,251 @@
+"""Hand-written HIP inference engine for the SDDM hollow transformer (lib/networks/hollow_networks.py;
+reference TAUnSDDM/lib/networks/hollow_networks.py:668-755 + lib/models/models.py:495-525).
+
+Walks a built `BidirectionalTransformer2` once, keeps pointers to its fp32 parameters (torch Linear layout
+[out][in] is the [N][K] layout the GEMM kernel streams), allocates every intermediate for a batch size and
+records the forward as a flat list of pre-bound libctdd launches, replayed as one HIP graph:
+
+  embed (csrc/hollow_kernels.hip) -> per direction and layer: LayerNorm -> QKV GEMM -> masked attention ->
+  out-proj GEMM (+residual) -> LayerNorm -> fc1 GEMM (ReLU) -> fc2 GEMM (+residual) -> readout: two LayerNorms
+  into the key buffer, l2r+r2l, Q / K / V GEMMs, readout attention, out GEMM (+residual), FiLM residual MLPs
+  (GELU GEMMs, LayerNorm+FiLM), logits GEMM.
+
+All arithmetic is fp32 (GEMMs on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32): the network's
+bar is 1e-4 on the logits against the reference's golden outputs.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import native
+from .unet_engine import _ConvArgs, _lib as _unet_lib, SEG_1x1
+
+_P, _I, _F, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+class _EmbedArgs(C.Structure):
+    _fields_ = [("x64", _P), ("x32", _P), ("t", _P), ("w_in", _P), ("b_in", _P), ("pe", _P), ("B", _I), ("D", _I), ("E", _I),
+                ("S", _I), ("temb_scale", _F), ("l2r", _P), ("r2l", _P), ("temb", _P)]
+
+
+class _LnArgs(C.Structure):
+    _fields_ = [("x", _P), ("y", _P), ("x_bs", _I64), ("y_bs", _I64), ("out_bs", _I64), ("gamma", _P), ("beta", _P), ("eps", _F),
+                ("film", _P), ("film_stride", _I), ("B", _I), ("T", _I), ("E", _I), ("out", _P)]
+
+
+class _AttnArgs(C.Structure):
+    _fields_ = [("q", _P), ("k", _P), ("v", _P), ("q_bs", _I64), ("k_bs", _I64), ("v_bs", _I64), ("q_rs", _I), ("k_rs", _I),
+                ("v_rs", _I), ("B", _I), ("Tq", _I), ("Tk", _I), ("H", _I), ("hd", _I), ("mode", _I), ("scale", _F), ("out", _P),
+                ("out_rs", _I)]
+
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    lib = _unet_lib()
+    if not _sigs_done:
+        for name, argt in (("ctdd_hollow_embed", [_P, _P]), ("ctdd_hollow_layernorm", [_P, _P]),
+                           ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _I64, _I, _I64, _P]),
+                           ("ctdd_hollow_put_rows", [_P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P])):
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argt, _I
+        _sigs_done = True
+    return lib
+
+
+def supports(model):
+    net = getattr(model, "net", None)
+    if net is None or net.__class__.__name__ != "BidirectionalTransformer2":
+        return False
+    m = net.config.model
+    E, H = m.embed_dim, m.num_heads
+    return (not net.use_cat and m.transformer_norm_type == "prenorm" and m.qkv_dim == E and E % H == 0 and (E // H) % 4 == 0
+            and E // H <= 64 and E % 16 == 0 and m.mlp_dim % 16 == 0)
+
+
+class HollowEngine:
+    def __init__(self, model):
+        self.model, self.net = model, model.net
+        self.dev = next(self.net.parameters()).device
+        if self.dev.type != "cuda":
+            raise native.CtddError("HollowEngine needs the model on a GPU")
+        self._plans, self._wver = {}, None
+
+    def _weights_version(self):
+        return sum(p._version for p in self.net.parameters()) + 7919 * getattr(self.model, "_weights_version", 0)
+
+    # ------------------------------------------------------------------ plan
+    def _build(self, B, x_dtype):
+        net, lib, dev = self.net, _lib(), self.dev
+        m = net.config.model
+        E, H, S, mlp = m.embed_dim, m.num_heads, net.S, m.mlp_dim
+        D = int(m.concat_dim)
+        hd = E // H
+        st = type("Plan", (), {})()
+        plan, keep = [], []
+        st.x_in = torch.zeros((B, D), dtype=x_dtype, device=dev)
+        st.t_in = torch.zeros((B,), dtype=torch.float32, device=dev)
+        stream = lambda: torch.cuda.current_stream().cuda_stream
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+
+        def P(t):
+            return None if t is None else t.data_ptr()
+
+        def W(p):                                   # fp32 contiguous view of a parameter (kept alive)
+            t = p.detach().float().contiguous()
+            keep.append(t)
+            return t
+
+        def launch(fn, *args, label=None, flops=0):
+            def run():
+                rc = fn(*args, stream())
+                if rc != 0:
+                    raise native.CtddError(f"{fn.__name__} failed ({rc}): {lib.ctdd_last_error().decode()}")
+            run.label, run.flops = (fn.__name__, label), flops
+            plan.append(run)
+
+        def linear(x, rows, K, lin_w, lin_b, out, act=0, res=None, label=""):
+            """out[rows][N] = act(x[rows][K] @ W^T + b) (+ res) on the fp32 implicit-GEMM kernel."""
+            w = W(lin_w)
+            N = w.shape[0]
+            assert w.shape[1] == K and K % 16 == 0
+            a = _ConvArgs()
+            a.nseg = 1
+            a.seg[0].f32, a.seg[0].C, a.seg[0].kind = P(x), K, SEG_1x1
+            a.w_f32, a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = P(w), 1, rows, 1, rows, 1, N, K
+            a.bias = P(W(lin_b)) if lin_b is not None else None
+            a.res_f32 = P(res)
+            a.out_f32, a.act = P(out), act
+            keep.append(a)
+            bk = 32 if K % 32 == 0 else 16
+            bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
+            launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, 1, label=f"linear {label} {rows}x{K}->{N}", flops=2 * rows * K * N)
+
+        def layernorm(x, x_bs, T, Ed, norm, out, out_bs, y=None, y_bs=0, film=None, film_stride=0):
+            a = _LnArgs()
+            a.x, a.y, a.x_bs, a.y_bs, a.out_bs = P(x), P(y), x_bs, y_bs, out_bs
+            a.gamma, a.beta, a.eps = P(W(norm.weight)), P(W(norm.bias)), float(norm.eps)
+            a.film, a.film_stride, a.B, a.T, a.E, a.out = P(film), film_stride, B, T, Ed, P(out)
+            keep.append(a)
+            launch(lib.ctdd_hollow_layernorm, C.byref(a))
+
+        def attention(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, Tq, Tk, mode, out):
+            a = _AttnArgs()
+            a.q, a.k, a.v, a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = q, k, v, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs
+            a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale, a.out, a.out_rs = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd), P(out), E
+            keep.append(a)
+            launch(lib.ctdd_hollow_attention, C.byref(a), label=f"attention mode {mode} {Tq}x{Tk}")
+
+        R = B * D
+        # ---- embedding
+        st.l2r, st.r2l, st.temb = f32(B, D, E), f32(B, D, E), f32(B, E)
+        pe = net.module_l2r.pos_embed.pe[0, :D].to(dev).float().contiguous()
+        keep.append(pe)
+        ea = _EmbedArgs()
+        if x_dtype == torch.int64:
+            ea.x64 = P(st.x_in)
+        else:
+            ea.x32 = P(st.x_in)
+        ea.t, ea.w_in, ea.b_in, ea.pe = P(st.t_in), P(W(net.input_embedding.weight.reshape(-1))), P(W(net.input_embedding.bias)), P(pe)
+        ea.B, ea.D, ea.E, ea.S, ea.temb_scale = B, D, E, S, float(net.temb_scale)
+        ea.l2r, ea.r2l, ea.temb = P(st.l2r), P(st.r2l), P(st.temb)
+        keep.append(ea)
+        launch(lib.ctdd_hollow_embed, C.byref(ea))
+
+        # ---- the two causal stacks
+        ln_buf, qkv, ctx, hid = f32(R, E), f32(R, 3 * E), f32(R, E), f32(R, mlp)
+        keep.extend([ln_buf, qkv, ctx, hid])
+        for x, stack, mode in ((st.l2r, net.module_l2r, 0), (st.r2l, net.module_r2l, 1)):
+            for blk in stack.trans_block_layers:
+                sa, ff = blk.self_attention_block, blk.feed_forward_block
+                mha = sa.self_attention
+                layernorm(x, D * E, D, E, sa.norm, ln_buf, D * E)
+                linear(ln_buf, R, E, mha.in_proj_weight, mha.in_proj_bias, qkv, label="qkv")
+                attention(P(qkv), D * 3 * E, 3 * E, P(qkv) + 4 * E, D * 3 * E, 3 * E, P(qkv) + 8 * E, D * 3 * E, 3 * E, D, D, mode, ctx)
+                linear(ctx, R, E, mha.out_proj.weight, mha.out_proj.bias, x, res=x, label="attn out")     # in place: + inputs
+                layernorm(x, D * E, D, E, ff.norm, ln_buf, D * E)
+                linear(ln_buf, R, E, ff.mlp.fc1.weight, ff.mlp.fc1.bias, hid, act=1, label="fc1")
+                linear(hid, R, mlp, ff.mlp.fc2.weight, None, x, res=x, label="fc2")
+
+        # ---- attention readout
+        ro = net.readout_module
+        ca = ro.cross_attention
+        Tk = 2 * D + 1
+        allk = f32(B, Tk, E)
+        keep.append(allk)
+        launch(lib.ctdd_hollow_put_rows, P(st.temb), P(allk), Tk * E, B, E)
+        layernorm(st.l2r, D * E, D, E, ro.ln1, allk[:, 1:], Tk * E)
+        layernorm(st.r2l, D * E, D, E, ro.ln2, allk[:, D + 1:], Tk * E)
+        qin, raw = f32(R, E), f32(R, E)
+        launch(lib.ctdd_hollow_add, P(allk) + 4 * E, Tk * E, P(allk) + 4 * (D + 1) * E, Tk * E, P(qin), D * E, B, D * E)
+        launch(lib.ctdd_hollow_add, P(st.l2r), D * E, P(st.r2l), D * E, P(raw), D * E, B, D * E)
+        qb, kb, vb = f32(R, E), f32(B * Tk, E), f32(B * Tk, E)
+        keep.extend([qin, raw, qb, kb, vb])
+        linear(qin, R, E, ca.dense_query.weight, None, qb, label="readout q")
+        linear(allk, B * Tk, E, ca.dense_key.weight, ca.dense_key.bias, kb, label="readout k")
+        linear(allk, B * Tk, E, ca.dense_val.weight, ca.dense_val.bias, vb, label="readout v")
+        attention(P(qb), D * E, E, P(kb), Tk * E, E, P(vb), Tk * E, E, D, Tk, 2, ctx)
+        xr = f32(R, E)
+        keep.append(xr)
+        linear(ctx, R, E, ca.out_linear.weight, ca.out_linear.bias, xr, res=raw, label="readout out")
+
+        # ---- FiLM residual readout
+        rr = ro.model
+        E2 = 2 * E
+        tm_h, tm = f32(B, mlp), f32(B, 4 * E)
+        lin = [l for l in rr.mlp.layers if isinstance(l, torch.nn.Linear)]
+        linear(st.temb, B, E, lin[0].weight, lin[0].bias, tm_h, act=2, label="temb mlp 1")
+        linear(tm_h, B, mlp, lin[1].weight, lin[1].bias, tm, label="temb mlp 2")
+        h, r, rh, film = f32(R, E2), f32(R, E2), f32(R, mlp), f32(B, 4 * E)
+        keep.extend([tm_h, tm, h, r, rh, film])
+        linear(xr, R, E, rr.input_layer.weight, rr.input_layer.bias, h, label="readout in")
+        for i in range(rr.n_res):
+            mlp_i, ln_i = rr.resid_layers[2 * i], rr.resid_layers[2 * i + 1]
+            li = [l for l in mlp_i.layers if isinstance(l, torch.nn.Linear)]
+            linear(h, R, E2, li[0].weight, li[0].bias, rh, act=2, label="resid 1")
+            linear(rh, R, mlp, li[1].weight, li[1].bias, r, label="resid 2")
+            fl = f32(B, 4 * E)
+            keep.append(fl)
+            linear(tm, B, 4 * E, rr.film_layer[i].weight, rr.film_layer[i].bias, fl, label="film")
+            layernorm(h, D * E2, D, E2, ln_i, h, D * E2, y=r, y_bs=D * E2, film=fl, film_stride=4 * E)
+        st.logits = f32(B, D, rr.out_dim)
+        linear(h, R, E2, rr.logits_layer.weight, rr.logits_layer.bias, st.logits, label="logits")
+        st.plan, st.keep, st.graph = plan, keep, None
+        return st
+
+    # ------------------------------------------------------------------ execution
+    def _run_plan(self, st):
+        for step in st.plan:
+            step()
+
+    def __call__(self, x, times):
+        B = x.shape[0]
+        key = (B, x.dtype)
+        ver = self._weights_version()
+        if ver != self._wver:
+            self._plans.clear()
+            self._wver = ver
+        st = self._plans.get(key)
+        if st is None:
+            if x.dtype not in (torch.int64, torch.int32):
+                raise native.CtddError(f"HollowEngine expects integer states, got {x.dtype}")
+            st = self._plans[key] = self._build(B, x.dtype)
+            st.x_in.copy_(x.reshape(st.x_in.shape))
+            st.t_in.copy_(times.float())
+            self._run_plan(st)
+            torch.cuda.synchronize()
+            if getattr(self.net.config.model, "engine_graph", True):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run_plan(st)
+                st.graph = g
+        st.x_in.copy_(x.reshape(st.x_in.shape))
+        st.t_in.copy_(times.float())
+        if st.graph is not None:
+            st.graph.replay()
+        else:
+            self._run_plan(st)
+        return st.logits

@@ -108,9 +108,25 @@ class HollowTransformer(nn.Module):
         else:
             raise ValueError(f"only nets='bidir_transformer2' is built (got {cfg.model.nets})")
         self.net = _maybe_ddp(net, cfg, rank)
+        self.cfg = cfg
+        self._engine = None
 
     def forward(self, x, times):
+        if self._use_engine(x):
+            from ctdd import hollow_engine
+            if self._engine is None:
+                self._engine = hollow_engine.HollowEngine(self)
+            return self._engine(x, times)
         return self.net(x, times)
+
+    # -- hand-written HIP inference engine (ctdd/hollow_engine.py); training keeps autograd ops
+    def _use_engine(self, x):
+        if torch.is_grad_enabled() or self.training or not x.is_cuda or x.dtype not in (torch.int64, torch.int32):
+            return False
+        if getattr(self.cfg.model, "engine", "hip") != "hip":
+            return False
+        from ctdd import hollow_engine
+        return hollow_engine.supports(self)
 
 
 class EMA:

@@ -1,0 +1,47 @@
+/* ctdd_hollow.h -- C ABI of the hollow-transformer inference kernels (libctdd.so, gfx950).
+ * Reference: TAUnSDDM/lib/networks/hollow_networks.py (BidirectionalTransformer2 668-755 and the blocks it
+ * is built from), lib/models/models.py:495-525.  fp32 device buffers, caller-owned; every call enqueues on
+ * `stream` (a hipStream_t) and returns 0 or a negative CTDD_E* code (ctdd_last_error() has the message).
+ * The linear layers of the network run on ctdd_unet_conv (ctdd_unet.h) with a 1x1 segment per input. */
+#ifndef CTDD_HOLLOW_H
+#define CTDD_HOLLOW_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* token sequences of the two causal directions (hollow_networks.py:729-753, 534-563, 1136-1156):
+ * temb = [sin | cos](t * temb_scale * f_j); x_embed = Linear(1->E)(2 x/(S-1) - 1);
+ * l2r = [temb, x_0..x_{D-2}] + pe, r2l = [x_1..x_{D-1}, temb] + pe */
+typedef struct {
+  const int64_t* x64; const int32_t* x32; const float* t; const float* w_in; const float* b_in; const float* pe;
+  int B, D, E, S; float temb_scale; float* l2r; float* r2l; float* temb;
+} ctdd_hollow_embed_args;
+int ctdd_hollow_embed(const void* embed_args, void* stream);
+
+/* out[b][j] = FiLM_b(LayerNorm(x[b][j] (+ y[b][j]))) with batch strides (in floats) on every operand
+ * (nn.LayerNorm in SelfAttentionBlock 311-340, FeedForwardBlock 343-420, AttentionReadout 283-308, ResidualReadout 90-132;
+ * apply_film: a = film[b][0:E], b = film[b][E:2E]) */
+typedef struct {
+  const float* x; const float* y; int64_t x_bs, y_bs, out_bs; const float* gamma; const float* beta; float eps;
+  const float* film; int film_stride; int B, T, E; float* out;
+} ctdd_hollow_ln_args;
+int ctdd_hollow_layernorm(const void* ln_args, void* stream);
+
+int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, int64_t out_bs, int B,
+                    int64_t per_batch, void* stream);                                   /* l2r + r2l */
+int ctdd_hollow_put_rows(const float* src, float* dst, int64_t dst_bs, int B, int E, void* stream);   /* temb into key slot 0 */
+
+/* masked multi-head attention, softmax(scale q.k) v: mode 0 causal (j <= i, UniDirectionalTransformer l2r 534-560),
+ * 1 anti-causal (j >= i, r2l), 2 readout over [temb | l2r | r2l] with Tk = 2 Tq + 1 (CrossAttention 204-280).
+ * q/k/v rows at base + b*bs + row*rs + head*hd. */
+typedef struct {
+  const float* q; const float* k; const float* v; int64_t q_bs, k_bs, v_bs; int q_rs, k_rs, v_rs;
+  int B, Tq, Tk, H, hd, mode; float scale; float* out; int out_rs;
+} ctdd_hollow_attn_args;
+int ctdd_hollow_attention(const void* attn_args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTDD_HOLLOW_H */

@@ -1,0 +1,68 @@
+"""GPU: the hollow-transformer inference engine (csrc/hollow_kernels.hip + the fp32 GEMM kernel, driven by
+ctdd/hollow_engine.py) against the reference's golden logits (tests/golden/hollow.npz) and against the
+autograd module at the maze configuration's size."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+def _tiny(golden, tag):
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from config.maze_config.config_hollow_maze import get_config
+    g = golden("hollow")
+    meta = ast.literal_eval(str(g[f"{tag}__cfg"]))
+    cfg = get_config()
+    cfg.device = "cuda"
+    cfg.data.S = meta["S"]
+    cfg.model.update(concat_dim=meta["D"], embed_dim=meta["embed_dim"], num_layers=meta["num_layers"], num_heads=meta["num_heads"],
+                     mlp_dim=meta["mlp_dim"], qkv_dim=meta["embed_dim"], readout_dim=meta["S"], t_func=meta["t_func"])
+    model = mu.create_model(cfg, torch.device("cuda"))
+    pre = f"{tag}__sd__"
+    sd = {k[len(pre):]: T(v).cuda() for k, v in g.items() if k.startswith(pre)}
+    missing, unexpected = torch.nn.Module.load_state_dict(model, sd, strict=False)
+    assert not missing and not unexpected
+    model.init_ema()
+    model.eval()
+    return cfg, model, T(g[f"{tag}__x"]).cuda(), T(g[f"{tag}__t"]).cuda(), g[f"{tag}__out"]
+
+
+@pytest.mark.parametrize("tag", ["s3", "s2"])
+def test_hollow_engine_matches_reference_golden(golden, tag):
+    from ctdd.hollow_engine import HollowEngine, supports
+    cfg, model, x, t, ref = _tiny(golden, tag)
+    assert supports(model)
+    with torch.no_grad():
+        out = HollowEngine(model)(x.long(), t).cpu().numpy()
+        via_model = model(x.long(), t).cpu().numpy()                # the wrapper routes eval/no_grad calls to the engine
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)         # BASELINE bar
+    np.testing.assert_array_equal(via_model, out)
+    model.train()
+
+
+def test_hollow_engine_matches_module_maze():
+    """config_hollow_maze (D=225, S=3, E=128, 8 layers per direction, 7.8 M parameters), batch 5."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from config.maze_config.config_hollow_maze import get_config
+    from ctdd.hollow_engine import HollowEngine
+    cfg = get_config()
+    cfg.device = "cuda"
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    x = torch.randint(0, 3, (5, 225), device="cuda")
+    t = torch.tensor([0.02, 0.3, 0.5, 0.8, 0.99], device="cuda")
+    with torch.no_grad():
+        cfg.model.engine = "torch"
+        ref = model(x, t).cpu()
+        out = HollowEngine(model)(x, t).cpu()
+    assert ref.shape == out.shape == (5, 225, 3)
+    assert (out - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0)
+    model.train()
