@@ -91,70 +91,103 @@ __global__ __launch_bounds__(256) void k_hollow_put_rows(const float* __restrict
 // ------------------------------------------------------------------ masked attention, online softmax
 // q rows (b, i): q + b*q_bs + i*q_rs + h*hd ; k / v likewise; out (b, i): out + (b*Tq + i)*E_out + h*hd.
 // mode 0: key j allowed iff j <= i ; 1: j >= i ; 2 (readout, Tk = 2 Tq + 1): j == 0 | 1 <= j <= Tq: j-1 <= i | j > Tq: j-Tq-1 >= i.
-// One workgroup = 64 queries of one (b, head); a query is served by 4 lanes that split the head dimension
-// (hd <= 64, multiple of 4); keys come through LDS in chunks of 64.
 struct HollowAttnArgs {
   const float* q; const float* k; const float* v;
   int64_t q_bs, k_bs, v_bs; int q_rs, k_rs, v_rs;
   int B, Tq, Tk, H, hd, mode; float scale;
   float* out; int out_rs;
 };
-constexpr int AQ = 64, AK = 64;
-__global__ __launch_bounds__(256) void k_hollow_attention(const HollowAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // K chunk [AK][hd] | V chunk [AK][hd]
-  const int hd = a.hd, b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AQ;
-  float* Ks = sm;
-  float* Vs = sm + AK * hd;
-  const int qi = threadIdx.x >> 2, part = threadIdx.x & 3, per = hd / 4;
-  const int i = i0 + qi;
+// One thread = one query with the whole head dimension in registers (q[HD], acc[HD]); a workgroup = 128
+// consecutive queries of one (b, head); keys / values come through LDS in chunks of 32 and are read as
+// wave-uniform (broadcast) float4s, so the inner loop is 2 HD FMAs per key against HD/2 LDS reads.
+// Keys are consumed four at a time: one running-max update and five exps per four keys.
+constexpr int AQ = 128, AK = 32;
+template <int HD>
+__global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[AK * HD];
+  __shared__ __attribute__((aligned(16))) float Vs[AK * HD];
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AQ;
+  const int i = i0 + threadIdx.x;
   const bool qok = i < a.Tq;
-  float qv[16], acc[16];
+  float qv[HD], acc[HD];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) { qv[c] = 0.0f; acc[c] = 0.0f; }
-  if (qok)
-    for (int c = 0; c < per; ++c) qv[c] = a.q[(size_t)b * a.q_bs + (size_t)i * a.q_rs + h * hd + part * per + c] * a.scale;
+  for (int c = 0; c < HD; ++c) { acc[c] = 0.0f; qv[c] = 0.0f; }
+  if (qok) {
+    const float* qr = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 u = *(const float4*)(qr + c);
+      qv[c] = u.x * a.scale; qv[c + 1] = u.y * a.scale; qv[c + 2] = u.z * a.scale; qv[c + 3] = u.w * a.scale;
+    }
+  }
   float m = -INFINITY, l = 0.0f;
-  // key range that any query of this block may see
-  const int ilo = i0, ihi = min(i0 + AQ, a.Tq) - 1;
+  const int ilo = i0, ihi = min(i0 + AQ, a.Tq) - 1;           // query range of the workgroup
+  auto allowed = [&](int j) {
+    if (a.mode == 0) return j <= i;
+    if (a.mode == 1) return j >= i;
+    return j == 0 || (j <= a.Tq ? j - 1 <= i : j - a.Tq - 1 >= i);
+  };
   for (int j0 = 0; j0 < a.Tk; j0 += AK) {
     const int j1 = min(j0 + AK, a.Tk) - 1;
-    bool any;
+    bool any;                                                  // does any query of the workgroup see this chunk? (uniform)
     if (a.mode == 0) any = j0 <= ihi;
     else if (a.mode == 1) any = j1 >= ilo;
     else any = j0 == 0 || (j0 <= a.Tq && j0 - 1 <= ihi) || (j1 > a.Tq && j1 - a.Tq - 1 >= ilo);
-    if (!any) continue;                              // (uniform over the workgroup)
+    if (!any) continue;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < AK * hd; idx += 256) {
-      const int jj = idx / hd, c = idx % hd, j = j0 + jj;
-      Ks[idx] = j < a.Tk ? a.k[(size_t)b * a.k_bs + (size_t)j * a.k_rs + h * hd + c] : 0.0f;
-      Vs[idx] = j < a.Tk ? a.v[(size_t)b * a.v_bs + (size_t)j * a.v_rs + h * hd + c] : 0.0f;
+    for (int idx = threadIdx.x; idx < AK * HD / 4; idx += AQ) {
+      const int jj = idx / (HD / 4), c4 = idx % (HD / 4), j = j0 + jj;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (j < a.Tk) {
+        kv = *(const float4*)(a.k + (size_t)b * a.k_bs + (size_t)j * a.k_rs + h * HD + c4 * 4);
+        vv = *(const float4*)(a.v + (size_t)b * a.v_bs + (size_t)j * a.v_rs + h * HD + c4 * 4);
+      }
+      *(float4*)(Ks + jj * HD + c4 * 4) = kv;
+      *(float4*)(Vs + jj * HD + c4 * 4) = vv;
     }
     __syncthreads();
+    if (!qok) continue;
     const int nj = j1 - j0 + 1;
-    for (int jj = 0; jj < nj; ++jj) {
-      const int j = j0 + jj;
-      bool ok;
-      if (a.mode == 0) ok = j <= i;
-      else if (a.mode == 1) ok = j >= i;
-      else ok = j == 0 || (j <= a.Tq ? j - 1 <= i : j - a.Tq - 1 >= i);
-      float s = 0.0f;
-      const float* kr = Ks + jj * hd + part * per;
-      for (int c = 0; c < per; ++c) s = fmaf(qv[c], kr[c], s);
-      s += __shfl_xor(s, 1, WAVE);
-      s += __shfl_xor(s, 2, WAVE);
-      if (ok && qok) {
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn), p = expf(s - mn);
-        l = l * corr + p;
-        const float* vr = Vs + jj * hd + part * per;
-        for (int c = 0; c < per; ++c) acc[c] = fmaf(p, vr[c], acc[c] * corr);
-        m = mn;
+    for (int jj = 0; jj < nj; jj += 4) {
+      float s[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float d = 0.0f;
+        const float* kr = Ks + (jj + u) * HD;                  // (rows past nj hold zeros or stale keys: masked below)
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+          const float4 kv = *(const float4*)(kr + c);
+          d = fmaf(qv[c], kv.x, d); d = fmaf(qv[c + 1], kv.y, d); d = fmaf(qv[c + 2], kv.z, d); d = fmaf(qv[c + 3], kv.w, d);
+        }
+        s[u] = (jj + u < nj && allowed(j0 + jj + u)) ? d : -INFINITY;
       }
+      const float mn = fmaxf(fmaxf(m, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
+      if (mn == -INFINITY) continue;                           // nothing visible yet
+      const float corr = expf(m - mn);
+      float p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = expf(s[u] - mn);       // exp(-inf) = 0 for masked keys
+      l = l * corr + ((p[0] + p[1]) + (p[2] + p[3]));
+#pragma unroll
+      for (int c = 0; c < HD; ++c) acc[c] *= corr;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* vr = Vs + (jj + u) * HD;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+          const float4 vv = *(const float4*)(vr + c);
+          acc[c] = fmaf(p[u], vv.x, acc[c]); acc[c + 1] = fmaf(p[u], vv.y, acc[c + 1]);
+          acc[c + 2] = fmaf(p[u], vv.z, acc[c + 2]); acc[c + 3] = fmaf(p[u], vv.w, acc[c + 3]);
+        }
+      }
+      m = mn;
     }
   }
   if (qok) {
     const float inv = 1.0f / l;
-    for (int c = 0; c < per; ++c) a.out[((size_t)b * a.Tq + i) * a.out_rs + h * hd + part * per + c] = acc[c] * inv;
+    float* o = a.out + ((size_t)b * a.Tq + i) * a.out_rs + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) *(float4*)(o + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
   }
 }
 
@@ -197,10 +230,19 @@ extern "C" int ctdd_hollow_put_rows(const float* src, float* dst, int64_t dst_bs
 extern "C" int ctdd_hollow_attention(const void* args_, void* stream) {
   const HollowAttnArgs& a = *(const HollowAttnArgs*)args_;
   CTDD_REQUIRE(a.q && a.k && a.v && a.out, CTDD_EINVAL, "hollow attention: null buffer");
-  CTDD_REQUIRE(a.hd % 4 == 0 && a.hd >= 4 && a.hd <= 64, CTDD_ERANGE, "hollow attention: head dim %d (multiple of 4, <= 64)", a.hd);
   CTDD_REQUIRE(a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || a.Tk == 2 * a.Tq + 1) && (a.mode == 2 || a.Tk == a.Tq), CTDD_EINVAL,
                "hollow attention: mode %d with Tq=%d Tk=%d", a.mode, a.Tq, a.Tk);
-  const size_t lds = (size_t)2 * AK * a.hd * sizeof(float);
-  hipLaunchKernelGGL(k_hollow_attention, dim3((a.Tq + AQ - 1) / AQ, a.H, a.B), dim3(256), lds, (hipStream_t)stream, a);
+  CTDD_REQUIRE(a.q_rs % 4 == 0 && a.k_rs % 4 == 0 && a.v_rs % 4 == 0 && a.out_rs % 4 == 0 && a.q_bs % 4 == 0 && a.k_bs % 4 == 0 && a.v_bs % 4 == 0,
+               CTDD_EINVAL, "hollow attention: strides must be multiples of 4 floats");
+  const dim3 g((a.Tq + AQ - 1) / AQ, a.H, a.B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.hd) {
+    case 4: hipLaunchKernelGGL(k_hollow_attention<4>, g, dim3(AQ), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(k_hollow_attention<8>, g, dim3(AQ), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(k_hollow_attention<16>, g, dim3(AQ), 0, st, a); break;
+    case 32: hipLaunchKernelGGL(k_hollow_attention<32>, g, dim3(AQ), 0, st, a); break;
+    case 64: hipLaunchKernelGGL(k_hollow_attention<64>, g, dim3(AQ), 0, st, a); break;
+    default: CTDD_REQUIRE(false, CTDD_ERANGE, "hollow attention: head dim %d (4, 8, 16, 32 or 64)", a.hd);
+  }
   return finish_launch("k_hollow_attention");
 }

@@ -62,8 +62,8 @@ def supports(model):
         return False
     m = net.config.model
     E, H = m.embed_dim, m.num_heads
-    return (not net.use_cat and m.transformer_norm_type == "prenorm" and m.qkv_dim == E and E % H == 0 and (E // H) % 4 == 0
-            and E // H <= 64 and E % 16 == 0 and m.mlp_dim % 16 == 0)
+    return (not net.use_cat and m.transformer_norm_type == "prenorm" and m.qkv_dim == E and E % H == 0 and (E // H) in (4, 8, 16, 32, 64)
+            and E % 16 == 0 and m.mlp_dim % 16 == 0)
 
 
 class HollowEngine:
