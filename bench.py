@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU (SURVEY 8d: 256)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
     return ap.parse_args()
 
 
@@ -105,30 +106,34 @@ def network_roofline(model, batch):
     eng = getattr(model, "_engine", None)
     if eng is None:
         return None
-    plans = [st for (b, _), st in eng._plans.items() if b == batch]
+    plans = []
+    for key, st in eng._plans.items():
+        if key[0] != batch:
+            continue
+        plans.extend(st[1] if isinstance(st, tuple) else [st])       # (logits, sub-plans, streams) when the batch runs as sub-batches
     if not plans:
         return None
-    st = plans[0]
-    eng._run_plan(st)
-    torch.cuda.synchronize()
     flops, secs, n = 0, 0.0, 0
-    for step in st.plan:
-        if not getattr(step, "flops", 0):
-            continue
-        step()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
+    for st in plans:
+        eng._run_plan(st)
+        torch.cuda.synchronize()
+        for step in st.plan:
+            if not getattr(step, "flops", 0):
+                continue
             step()
-        e1.record()
-        e1.synchronize()
-        secs += e0.elapsed_time(e1) * 1e-3 / 3
-        flops += step.flops
-        n += 1
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                step()
+            e1.record()
+            e1.synchronize()
+            secs += e0.elapsed_time(e1) * 1e-3 / 3
+            flops += step.flops
+            n += 1
     ach = flops / secs / 1e12
     return {"kernel": "ctdd k_conv_ring / k_conv_patch / k_conv_igemm (bf16 implicit-GEMM convolutions of the score network)", "bound": "mfma",
             "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5),
-            "traffic": None, "launches_per_forward": n, "sum_launch_us": round(secs * 1e6, 1), "matrix_gflop_per_forward": round(flops / 1e9, 1)}
+            "traffic": None, "sub_batches": len(plans), "launches_per_forward": n, "sum_launch_us": round(secs * 1e6, 1), "matrix_gflop_per_forward": round(flops / 1e9, 1)}
 
 
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
@@ -177,14 +182,24 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libctdd has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    if local >= ndev and os.environ.get("CTDD_BENCH_SHARE_DEVICE") != "1":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local_dev = local % ndev                 # (CTDD_BENCH_SHARE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CTDD_BENCH_BACKEND", "nccl")      # nccl = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     cfg, model, sampler = build_model(dev)
+    if a.engine_streams is not None:
+        cfg.model.engine_streams = a.engine_streams
     sampler.seed = 42
     sampler.rank_stream = rank              # distinct Philox key per rank; no data-path collective
     K, W = a.steps, a.warmup

@@ -137,7 +137,7 @@ class UNetEngine:
         self._stats_off += n
         return off
 
-    def _build(self, B, x_dtype):
+    def _build(self, B, x_dtype, logits_out=None):
         net, m = self.net, self.cfg.model
         lib = _lib()
         dev = self.dev
@@ -418,14 +418,14 @@ class UNetEngine:
             st.net_out = torch.empty((B * H0 * W0, n_out), dtype=torch.float32, device=dev)
             conv([(ao, ao.C, SEG_3x3)], self._conv_w(oc.weight.detach().float(), [ao.C]),
                  oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.net_out)
-            st.logits = torch.empty((B, D, S), dtype=torch.float32, device=dev)
+            st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=torch.float32, device=dev)
             la = _LogisticArgs()
             la.net, la.x0, la.B, la.C, la.HW, la.S, la.fix, la.out = (ptr(st.net_out), ptr(st.x0), B, Cin, H0 * W0, S,
                                                                      int(bool(m.fix_logistic)), ptr(st.logits))
             keep.append(la)
             launch(lib.ctdd_unet_logistic_head, C.byref(la))
         else:
-            st.logits = torch.empty((B, D, S), dtype=torch.float32, device=dev)
+            st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=torch.float32, device=dev)
             conv([(ao, ao.C, SEG_3x3)], self._conv_w(oc.weight.detach().float(), [ao.C]),
                  oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.logits,
                  logits_C=Cin)
@@ -454,31 +454,78 @@ class UNetEngine:
         for step in st.plan:
             step()
 
+    def _prepare(self, B, x_dtype, x, times, logits_out=None):
+        """Build, warm up and capture the plan for (B, dtype)."""
+        st = self._build(B, x_dtype, logits_out)
+        st.x_in.copy_(x.reshape(st.x_in.shape))
+        st.t_in.copy_(times.float())
+        self._run_plan(st)                    # eager warm-up (also sets the LDS attributes)
+        torch.cuda.synchronize()
+        if getattr(self.cfg.model, "engine_graph", True):
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run_plan(st)
+                st.graph = g
+            except Exception:                 # capture unsupported: keep eager launches
+                st.graph = None
+                torch.cuda.synchronize()
+        return st
+
+    @staticmethod
+    def _replay(st, x, times):
+        st.x_in.copy_(x.reshape(st.x_in.shape))
+        st.t_in.copy_(times.float())
+        if st.graph is not None:
+            st.graph.replay()
+        else:
+            for step in st.plan:              # (stats / split-K pools are zeroed inside _run_plan for the eager path)
+                pass
+            raise native.CtddError("eager replay goes through _run_plan")
+
     def __call__(self, x, times):
         B = x.shape[0]
-        key = (B, x.dtype)
         ver = self._weights_version()
         if ver != self._wver:                     # weights changed (optimizer step, EMA swap): re-pack
             self._plans.clear()
             self._wver = ver
+        if x.dtype not in (torch.int64, torch.int32):
+            raise native.CtddError(f"UNetEngine expects integer states, got {x.dtype}")
+        # Sub-batches on parallel streams: samples are independent, and two half-size forwards in flight fill the
+        # CUs that one forward leaves idle (half-empty last rounds of the 392-tile grids, 98-workgroup 7x7 levels).
+        nsub = int(getattr(self.cfg.model, "engine_streams", 2))
+        if nsub > 1 and B % nsub == 0 and B // nsub >= 32 and getattr(self.cfg.model, "engine_graph", True):
+            key = (B, x.dtype, nsub)
+            grp = self._plans.get(key)
+            Bs = B // nsub
+            xs = x.reshape(B, -1)
+            if grp is None:
+                C_, H_, W_ = self.cfg.data.shape
+                logits = torch.empty((B, C_ * H_ * W_, self.net.S), dtype=torch.float32, device=self.dev)
+                subs = [self._prepare(Bs, x.dtype, xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs], logits[i * Bs:(i + 1) * Bs])
+                        for i in range(nsub)]
+                grp = self._plans[key] = (logits, subs, [torch.cuda.Stream(device=self.dev) for _ in range(nsub - 1)])
+            logits, subs, streams = grp
+            if all(s.graph is not None for s in subs):
+                main = torch.cuda.current_stream()
+                ready = torch.cuda.Event()
+                ready.record(main)
+                done = []
+                for i in range(1, nsub):
+                    with torch.cuda.stream(streams[i - 1]):
+                        streams[i - 1].wait_event(ready)
+                        self._replay(subs[i], xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs])
+                        ev = torch.cuda.Event()
+                        ev.record(streams[i - 1])
+                        done.append(ev)
+                self._replay(subs[0], xs[:Bs], times[:Bs])
+                for ev in done:
+                    main.wait_event(ev)
+                return logits
+        key = (B, x.dtype)
         st = self._plans.get(key)
         if st is None:
-            if x.dtype not in (torch.int64, torch.int32):
-                raise native.CtddError(f"UNetEngine expects integer states, got {x.dtype}")
-            st = self._plans[key] = self._build(B, x.dtype)
-            st.x_in.copy_(x.reshape(st.x_in.shape))
-            st.t_in.copy_(times.float())
-            self._run_plan(st)                    # eager warm-up (also sets the LDS attributes)
-            torch.cuda.synchronize()
-            if getattr(self.cfg.model, "engine_graph", True):
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._run_plan(st)
-                    st.graph = g
-                except Exception:                 # capture unsupported: keep eager launches
-                    st.graph = None
-                    torch.cuda.synchronize()
+            st = self._plans[key] = self._prepare(B, x.dtype, x, times)
         st.x_in.copy_(x.reshape(st.x_in.shape))
         st.t_in.copy_(times.float())
         if st.graph is not None:
