@@ -432,3 +432,116 @@ extern "C" int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const in
   hipLaunchKernelGGL(k_elbo_bwd, dim3((D + LRB - 1) / LRB, B), dim3(256), 0, st, a);
   return finish_launch("k_elbo_bwd");
 }
+
+// ================================================================== K12b: ScoreElbo (direct logits), value + d/dlogits
+// Reference lib/losses/losses.py:1255-1500: the CT-ELBO with SDDM ratios exp(ll_all - ll_xt).  Per row (b,d),
+// ll = log_softmax(l), x = x~_bd, xr = reg_x_bd (= x~ with one forward pass, x_t with two), dd[s] = ll[s] - ll[x]:
+//   reg_row   = sum_s e^{dd[s]} [s != xr] R[s,xr]
+//   outer_row = sum_s Wt[s] dd[s],  Wt[s] = [s != x] R[s,x] q[x0,s] / (q[x0,x] + eps);  norm_row as in K11
+//   loss = mean_b(-sum_d outer / sum_d norm) + mean_b sum_d reg + (nll_weight / B) sum_{b,d} -ll[x]
+// g[s] = d loss / d dd[s] = e^{dd[s]} [s != xr] R[s,xr] / B + c_b Wt[s]  (s != x),  c_b = -1 / (B norm_b);
+// g[x] = -sum_{s != x} g[s] - nll_weight / B;  dl[j] = g[j] - p[j] sum_s g[s].
+// One wave per row; forward rows -> per-sample normalisers (k_elbo_reduce) -> backward rows.
+namespace ctdd {
+
+__global__ __launch_bounds__(256) void k_selbo_fwd(const ElboArgs a, const int32_t* __restrict__ regx) {
+  const int lane = threadIdx.x & 63, S = a.S, D = a.D;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)a.B * D) return;
+  const int b = (int)(row / D);
+  const float* l = a.logits + (size_t)row * S;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* R = a.R + (size_t)b * S * S;
+  const int x = min(max(a.xt[row], 0), S - 1), x0 = min(max(a.x0[row], 0), S - 1), xr = min(max(regx[row], 0), S - 1);
+  float m = -INFINITY;
+  for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
+  m = lwave_max(m);
+  float z = 0.0f;
+  for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
+  const float L = m + logf(lwave_sum(z));
+  const float llx = l[x] - L;
+  const float qx0xt = q[(size_t)x0 * S + x] + a.eps, bsum = a.base_sum[b], rsx = -R[(size_t)x * S + x];
+  float reg = 0.0f, outer = 0.0f, norm = 0.0f;
+  for (int s = lane; s < S; s += 64) {
+    const float dd = (l[s] - L) - llx;
+    if (s != xr) reg += expf(dd) * R[(size_t)s * S + xr];
+    if (s != x) {
+      const float orate = R[(size_t)s * S + x], qx0 = q[(size_t)x0 * S + s];
+      const float Z = bsum - rsx - R[(size_t)s * S + s];
+      outer += orate * (qx0 / qx0xt) * dd;
+      norm += orate * qx0 / (Z * qx0xt);
+    }
+  }
+  reg = lwave_sum(reg); outer = lwave_sum(outer); norm = lwave_sum(norm);
+  if (lane == 0) {
+    double* dst = a.rows + (size_t)row * 4;
+    dst[0] = outer; dst[1] = norm; dst[2] = reg; dst[3] = -llx;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_selbo_bwd(const ElboArgs a, const int32_t* __restrict__ regx) {
+  const int lane = threadIdx.x & 63, S = a.S, D = a.D;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)a.B * D) return;
+  const int b = (int)(row / D);
+  const float* l = a.logits + (size_t)row * S;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* R = a.R + (size_t)b * S * S;
+  float* gr = a.grad + (size_t)row * S;
+  const int x = min(max(a.xt[row], 0), S - 1), x0 = min(max(a.x0[row], 0), S - 1), xr = min(max(regx[row], 0), S - 1);
+  const float cb = a.cb[b], invB = a.elbo_scale / (float)a.B;
+  float m = -INFINITY;
+  for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
+  m = lwave_max(m);
+  float z = 0.0f;
+  for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
+  const float L = m + logf(lwave_sum(z));
+  const float llx = l[x] - L;
+  const float qx0xt = q[(size_t)x0 * S + x] + a.eps;
+  auto gd = [&](int s) {                              // d loss / d dd[s], s != x
+    const float dd = (l[s] - L) - llx;
+    float g = cb * R[(size_t)s * S + x] * (q[(size_t)x0 * S + s] / qx0xt);
+    if (s != xr) g += invB * expf(dd) * R[(size_t)s * S + xr];
+    return g;
+  };
+  float gs = 0.0f;
+  for (int s = lane; s < S; s += 64)
+    if (s != x) gs += gd(s);
+  gs = lwave_sum(gs);
+  const float gx = -gs - a.nll_scale;                  // nll_scale = nll_weight / B here
+  const float gsum = gs + gx;
+  for (int s = lane; s < S; s += 64) {
+    const float p = expf(l[s] - L);
+    gr[s] = (s == x ? gx : gd(s)) - p * gsum;
+  }
+}
+
+}  // namespace ctdd
+
+extern "C" int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x,
+                                    const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
+                                    void* scratch, float* grad_logits, float* out_loss, void* stream) {
+  CTDD_REQUIRE(logits && x0 && x_tilde && reg_x && qt0 && rate && scratch && grad_logits && out_loss, CTDD_EINVAL, "score-elbo: null buffer");
+  CTDD_REQUIRE(B > 0 && D > 0 && S >= 2 && S <= 256, CTDD_ERANGE, "score-elbo: B=%d D=%d S=%d (S <= 256)", B, D, S);
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  unsigned char* sp = (unsigned char*)scratch;          // same layout as ctdd_ctelbo_scratch_bytes
+  ElboArgs a;
+  a.logits = logits; a.x0 = x0; a.xt = x_tilde; a.q = qt0; a.qT = qt0; a.R = rate;
+  a.B = B; a.D = D; a.S = S; a.eps = eps; a.elbo_scale = 1.0f; a.nll_scale = nll_scale;
+  a.Atab = (float*)sp; sp += al((int64_t)B * S * S * 4);
+  a.u = (float*)sp; sp += al((int64_t)B * D * S * 4);
+  a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
+  a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
+  a.cb = (float*)sp;
+  a.grad = grad_logits; a.out_loss = out_loss;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * D;
+  hipLaunchKernelGGL(k_elbo_atab, dim3(1, B), dim3(256), 0, st, a);          // (first column block only: base_sum; its A rows are unused scratch)
+  if (int rc = finish_launch("k_elbo_atab")) return rc;
+  hipLaunchKernelGGL(k_selbo_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, reg_x);
+  if (int rc = finish_launch("k_selbo_fwd")) return rc;
+  hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a);
+  if (int rc = finish_launch("k_elbo_reduce")) return rc;
+  hipLaunchKernelGGL(k_selbo_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, reg_x);
+  return finish_launch("k_selbo_bwd");
+}

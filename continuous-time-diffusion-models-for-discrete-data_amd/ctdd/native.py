@@ -50,6 +50,7 @@ _SIGS = {
     "ctdd_crm_loss": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_ctelbo_scratch_bytes": ([_I, _I, _I], _I64),
     "ctdd_ctelbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P], _I),
+    "ctdd_score_elbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_opt_chunk_elems": ([], _I),
     "ctdd_adam_ema_step": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
 }
@@ -250,6 +251,20 @@ def crm_loss(logits, xt, x0, qt0, loss_type, scale, nll_scale):
                                 _ptr(x0, torch.int32, "x0") if x0 is not None else None,
                                 _ptr(qt0, torch.float32, "qt0") if qt0 is not None else None, B, D, S, lt, float(scale),
                                 float(nll_scale), _ptr(grad), _ptr(rows), _ptr(out), _stream()), "ctdd_crm_loss")
+    return out[0], grad
+
+
+def score_elbo_loss(logits, x0, x_tilde, reg_x, qt0, rate, eps, nll_scale):
+    """(loss scalar tensor, d loss / d logits) of ScoreElbo with direct logits."""
+    B, D, S = logits.shape
+    lib = load()
+    scratch = torch.empty((int(lib.ctdd_ctelbo_scratch_bytes(B, D, S)),), dtype=torch.uint8, device=logits.device)
+    grad = torch.empty_like(logits)
+    out = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    _check(lib.ctdd_score_elbo_loss(_ptr(logits, torch.float32, "logits"), _ptr(x0, torch.int32, "x0"), _ptr(x_tilde, torch.int32, "x_tilde"),
+                                    _ptr(reg_x, torch.int32, "reg_x"), _ptr(qt0, torch.float32, "qt0"), _ptr(rate, torch.float32, "rate"),
+                                    B, D, S, float(eps), float(nll_scale), _ptr(scratch), _ptr(grad), _ptr(out), _stream()),
+           "ctdd_score_elbo_loss")
     return out[0], grad
 
 

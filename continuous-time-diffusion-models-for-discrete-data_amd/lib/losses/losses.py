@@ -190,6 +190,23 @@ def _crm_loss(cfg, model, xt, t, ll_all, ll_xt):
     raise ValueError("Unknown loss_type: %s" % lt)
 
 
+class _ScoreElboFn(torch.autograd.Function):
+    """ScoreElbo value and logit-gradient in HIP (csrc/losses.hip), direct logits."""
+
+    @staticmethod
+    def forward(ctx, logits, x0, x_tilde, reg_x, qt0, rate, eps, nll_scale):
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        val, grad = native.score_elbo_loss(logits.detach().float().contiguous(), i32(x0), i32(x_tilde), i32(reg_x), qt0.contiguous(),
+                                           rate.contiguous(), eps, nll_scale)
+        ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g,) + (None,) * 7
+
+
 class _CrmLossFn(torch.autograd.Function):
     """K12 (csrc/losses.hip): value and logit-gradient of the CRM objective in one HIP pass."""
 
@@ -309,6 +326,8 @@ class ScoreElbo:
         qt0, rate, x_t, x_tilde = _noise(model, x0, ts, True)
         reg_x = x_tilde if self.one_forward_pass else x_t
         logits = model(reg_x, ts)
+        if self.cfg.loss.logit_type == "direct" and logits.is_cuda and logits.shape[-1] <= 256 and getattr(self.cfg.loss, "fused", True):
+            return _ScoreElboFn.apply(logits, x0, x_tilde, reg_x, qt0, rate, float(eps), float(self.nll_weight) / B)
         n = torch.arange(B, device=x0.device).view(B, 1)
         rT = rate.transpose(1, 2)
         ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, x_tilde, ts, logits)

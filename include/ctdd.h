@@ -183,6 +183,13 @@ int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const int32_t* x_ti
                      const float* rate, int B, int D, int S, float eps, float elbo_scale, float nll_scale,
                      void* scratch, float* grad_logits, float* out_loss, void* stream);
 
+/* ---- ScoreElbo with direct logits (lib/losses/losses.py:1255-1500), value and d/dlogits:
+ * out_loss = mean_b(-sig_b / norm_b) + mean_b(reg_b) + nll_scale * sum_{b,d} -log_softmax(logits)[x~]   (nll_scale = nll_weight / B).
+ * reg_x = x~ with one forward pass, x_t with two (logits = model(reg_x)).  scratch: ctdd_ctelbo_scratch_bytes(B,D,S). */
+int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x,
+                         const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
+                         void* scratch, float* grad_logits, float* out_loss, void* stream);
+
 /* ---- K28: clip_grad_norm_ + Adam.step + EMA update over all parameter tensors in two launches
  * (lib/training/training.py:17-40, lib/models/models.py:745-758, torch.optim.Adam single-tensor formulas).
  * tensors: device array of ctdd_opt_tensor; chunks: device array of ctdd_opt_chunk covering every tensor in
