@@ -16,7 +16,13 @@ from lib.networks import unet
 
 
 def _maybe_ddp(net, cfg, rank):
-    return DDP(net, device_ids=[rank]) if cfg.distributed else net
+    """cfg.distributed: minibatch-sharded data parallelism, one gradient all-reduce per step (RCCL on GPUs)."""
+    if not cfg.distributed:
+        return net
+    on_gpu = next(net.parameters()).is_cuda
+    # find_unused_parameters: the hollow network carries two sub-modules its forward never uses (`embedding`, `temb_net`,
+    # hollow_networks.py:690-712); without the flag their bucket never reduces and the second step raises
+    return DDP(net, device_ids=[rank] if on_gpu else None, find_unused_parameters=True)
 
 
 def logistic_logits(mu, log_scale, S, fix_logistic, eps=1e-6):

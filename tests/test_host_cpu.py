@@ -281,3 +281,72 @@ def test_bookkeeping_roundtrip(tmp_path):
     for a, b in zip(model.parameters(), model2.parameters()):
         assert torch.equal(a, b)
     assert torch.equal(model.shadow_params[0], model2.shadow_params[0])
+
+
+# ------------------------------------------------------------------ data-parallel training (gloo, CPU, world size 2)
+class _MbLoss:
+    """A loss whose gradient depends on the rank's minibatch."""
+
+    def calc_loss(self, state, minibatch, label=None):
+        model = state["model"]
+        x = minibatch.long()
+        t = torch.full((x.shape[0],), 0.5)
+        return (model(x, t) ** 2).mean() * (1.0 + minibatch.float().mean())
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "continuous-time-diffusion-models-for-discrete-data_amd")]
+    mu, _, _, tu, ou = _load_lib()
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = get_config()
+    cfg.device, cfg.distributed = "cpu", True
+    cfg.model.dropout_rate = cfg.model.attention_dropout_rate = 0.0
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cpu"), rank=rank)
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 5}
+    g = torch.Generator().manual_seed(100 + rank)
+    mb = torch.randint(0, 2, (3, 32), generator=g)
+    tu.get_train_step(cfg).step(state, _MbLoss(), mb)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    q.put((rank, flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_training_step_world2_gloo():
+    """cfg.distributed: both ranks end the step with identical weights = the single-process step on the averaged gradient."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0], res[1])
+    # single-process reference: mean of the two ranks' losses
+    mu, _, _, tu, ou = _load_lib()
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    cfg = get_config()
+    cfg.device = "cpu"
+    cfg.model.dropout_rate = cfg.model.attention_dropout_rate = 0.0
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cpu"))
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 5}
+    mbs = [torch.randint(0, 2, (3, 32), generator=torch.Generator().manual_seed(100 + r)) for r in range(2)]
+
+    class Both:
+        def calc_loss(self, state, minibatch, label=None):
+            return 0.5 * (_MbLoss().calc_loss(state, mbs[0]) + _MbLoss().calc_loss(state, mbs[1]))
+
+    tu.get_train_step(cfg).step(state, Both(), mbs[0])
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+    np.testing.assert_allclose(res[0], ref, rtol=2e-5, atol=1e-7)
