@@ -1286,6 +1286,42 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnArgs a) {
   __syncthreads();
   const int vpp = C / 8;                                   // 8-channel vectors per pixel
   const int64_t nv = (int64_t)a.HW * vpp;
+  if (!a.s1_f32 && !a.out_f32 && nv < (int64_t)1 << 30) {
+    // bf16 in / bf16 out (the throughput mode): four 16-byte vectors in flight per thread, 32-bit index arithmetic
+    const unsigned n32 = (unsigned)nv, stride = gridDim.x * 256u, uvpp = (unsigned)vpp;
+    for (unsigned v0 = blockIdx.x * 256u + threadIdx.x; v0 < n32; v0 += 4u * stride) {
+      uint4 u[4];
+      unsigned c0[4];
+      size_t oo[4];
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned v = v0 + (unsigned)k * stride;
+        ok[k] = v < n32;
+        const unsigned px = ok[k] ? v / uvpp : 0u;
+        c0[k] = (ok[k] ? v - px * uvpp : 0u) * 8u;
+        const bool first = (int)c0[k] < a.C1;
+        const unsigned cc = first ? c0[k] : c0[k] - (unsigned)a.C1;
+        const size_t off = ((size_t)b * a.HW + px) * (first ? a.C1 : a.C2) + cc;
+        oo[k] = ((size_t)b * a.HW + px) * C + c0[k];
+        u[k] = ok[k] ? *(const uint4*)((first ? a.s1_bf16 : a.s2_bf16) + off) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        const unsigned w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = (j & 1) ? __uint_as_float(w[j >> 1] & 0xFFFF0000u) : __uint_as_float(w[j >> 1] << 16);
+          y[j] = fmaf(x, scale[c0[k] + j], shift[c0[k] + j]);
+          if (a.swish) y[j] = y[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[j]));       // hardware exp2 / rcp (1 ulp) before the bf16 rounding
+        }
+        *(uint4*)(a.out_hi + oo[k]) = make_uint4(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]), pack2_bf16(y[4], y[5]), pack2_bf16(y[6], y[7]));
+      }
+    }
+    return;
+  }
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256) {
     const int px = (int)(v / vpp), c0 = (int)(v % vpp) * 8;
     float x[8];
