@@ -172,7 +172,13 @@ __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, 
 // xt = this wave's [32][32*BNT + 4] fp32 region; rows wrow0 .. wrow0 + 32*MT of the output.
 template <int BNT, int MT>
 __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)[MT][BNT], float* xt, int64_t wrow0, int n0,
-                                          int64_t M, int HW, const TileStats& ts) {
+                                          int64_t M, int HW, const TileStats& ts, unsigned long long* epi_t = nullptr) {
+#ifdef CTDD_RES_STAMPS
+  unsigned long long e0, e1, e2, e3;
+#define ESTAMP(t_) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+#else
+#define ESTAMP(t_)
+#endif
   constexpr int BN = 32 * BNT, LD = BN + 4, CH = BN / 8, RS = 64 / CH, STEPS = (32 + RS - 1) / RS;
   const int lane = threadIdx.x & 63, li = lane & 31, g = lane >> 5;
   if (a.ksplit > 1) {                                     // partial sums only; k_conv_finish does the rest
@@ -200,11 +206,23 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
   for (int mt = 0; mt < MT; ++mt) {
     const int64_t base = wrow0 + mt * 32;
     if (base >= M) break;
+    ESTAMP(e0)
+    // residual pieces of this lane's rows: issued before the LDS passes so that their latency hides behind them
+    uint4 rres[STEPS];
+    if (a.res_bf16) {
+#pragma unroll
+      for (int step = 0; step < STEPS; ++step) {
+        const int row = step * RS + rsub;
+        const int64_t p = base + row;
+        rres[step] = (lane_ok && row < 32 && p < M) ? *(const uint4*)(a.res_bf16 + (size_t)p * a.N + nc) : make_uint4(0, 0, 0, 0);
+      }
+    }
     // ---- phase 1: column-per-lane accumulators -> row-major fp32 image
 #pragma unroll
     for (int t = 0; t < BNT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) xt[((r & 3) + 8 * (r >> 2) + 4 * g) * LD + t * 32 + li] = acc[mt][t][r];
+    ESTAMP(e1)
     // ---- phase 2: one lane per (row, 8-column piece)
     const int b_first = (int)(base / HW);
     const int64_t next_sample = (int64_t)(b_first + 1) * HW;   // a 32-row slice spans at most two samples (HW >= 32)
@@ -226,7 +244,7 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
         for (int j = 0; j < 8; ++j) v[j] += bv[j] + (second ? tb1[j] : tb0[j]);
         const size_t o = (size_t)p * a.N + nc;
         if (a.res_bf16) {
-          const uint4 rr = *(const uint4*)(a.res_bf16 + o);
+          const uint4 rr = rres[step];
           const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -254,6 +272,7 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
         }
       }
     }
+    ESTAMP(e2)
     // ---- phase 3: GroupNorm statistics, one lane per column down the slice's rows (fp64), so that the
     // LDS atomics are one per (sample, column, moment) and wave slice and hit distinct addresses
     // (a 64-bit LDS atomic costs ~75 cycles per wave-instruction, more when lanes share an address)
@@ -265,8 +284,22 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
         const int c = c0 + lane;
         if (c < BN && n0 + c < a.N) {
           double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-          for (int row = 0; row < split; ++row) { const double x = xt[row * LD + c]; s0 += x; q0 += x * x; }
-          for (int row = split; row < nrows; ++row) { const double x = xt[row * LD + c]; s1 += x; q1 += x * x; }
+#pragma unroll
+          for (int r8 = 0; r8 < 32; r8 += 8) {             // eight independent LDS reads in flight; fp32 sums of eight rows, fp64 across blocks
+            float xv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xv[k] = xt[(r8 + k) * LD + c];
+            float a0 = 0.0f, b0 = 0.0f, a1 = 0.0f, b1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int row = r8 + k;                      // (row < split, row < nrows: wave-uniform)
+              const float x0 = row < split ? xv[k] : 0.0f;
+              const float x1 = (row >= split && row < nrows) ? xv[k] : 0.0f;
+              a0 += x0; b0 = fmaf(x0, x0, b0);
+              a1 += x1; b1 = fmaf(x1, x1, b1);
+            }
+            s0 += (double)a0; q0 += (double)b0; s1 += (double)a1; q1 += (double)b1;
+          }
           double* st = ts.lds + ((size_t)(b_first - ts.b0) * ts.BN + c) * 2;
           atomicAdd(st, s0);
           atomicAdd(st + 1, q0);
@@ -277,6 +310,10 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
         }
       }
     }
+#ifdef CTDD_RES_STAMPS
+    ESTAMP(e3)
+    if (epi_t) { epi_t[0] += e1 - e0; epi_t[1] += e2 - e1; epi_t[2] += e3 - e2; }
+#endif
   }
 }
 // bytes of LDS the row-major epilogue needs for NW waves behind the statistics of `rows` output rows
@@ -870,6 +907,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
   static_assert(DEPTH == 1 || DEPTH == 2, "ring of two or three unit buffers");
   static_assert(OPS3 <= 18, "at most two DMA ops per tap");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef CTDD_RES_STAMPS
+  unsigned long long tentry;
+  RSTAMP(tentry)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, g = lane >> 5;
@@ -1120,7 +1161,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
     if (lane == 0 && a.acc_buf) {
       unsigned long long* o = (unsigned long long*)a.acc_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
       for (int i = 0; i < 5; ++i) o[i] = dur[i];
-      o[5] = tstart; o[6] = tend; o[7] = tend - tstart;
+      o[2] = tstart - tentry;                  // prologue (validity bits, segment table, offsets)
+      o[5] = tstart; o[6] = tend; o[7] = tend - tentry;
     }
   }
 #endif
@@ -1128,8 +1170,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
   const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
   if (!ts.lds) __syncthreads();
   float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
+#ifdef CTDD_RES_STAMPS
+  unsigned long long ept[3] = {0, 0, 0}, tep0, tep1;
+  RSTAMP(tep0)
+  conv_epilogue_rows<BNT, MT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts, ept);
+  RSTAMP(tep1)
+  tile_stats_flush(a, ts);
+  {
+    unsigned long long tdone;
+    RSTAMP(tdone)
+    if (lane == 0 && a.acc_buf) {
+      unsigned long long* o = (unsigned long long*)a.acc_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+      o[0] = ept[0]; o[1] = ept[1]; o[2] = ept[2];          // epilogue phases 1, 2, 3 (overwrite the dma-wait / barrier / prologue slots)
+      o[3] = tep0 - o[6];                                     // tile_stats_begin (barriers + zeroing)
+      o[4] = tdone - tep1;                                    // flush
+      o[7] = tdone - tentry;
+    }
+  }
+#else
   conv_epilogue_rows<BNT, MT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
   tile_stats_flush(a, ts);
+#endif
 }
 
 // split-K finish: acc_buf (+ bias, time bias, residual) -> outputs and GroupNorm statistics

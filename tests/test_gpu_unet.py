@@ -155,4 +155,5 @@ def test_slab_conv_kernels(kernel, B, H, W, segs, N, ksplit, bnt):
     assert (out - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
     assert torch.equal(out_hi, out.to(torch.bfloat16))
     want = torch.stack([out.double().view(B, H * W, N).sum(1), (out.double() ** 2).view(B, H * W, N).sum(1)], -1)
-    torch.testing.assert_close(stats, want, rtol=1e-12, atol=1e-9)
+    # fp32 sums over blocks of eight rows, fp64 above that: ~1e-7 of sqrt(n * sum of squares)
+    torch.testing.assert_close(stats, want, rtol=1e-5, atol=1e-3)
