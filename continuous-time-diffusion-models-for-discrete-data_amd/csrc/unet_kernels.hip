@@ -920,22 +920,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
   const int n0 = blockIdx.y * BN;
   const int halo = Wd + 1;
   const int Ntot = a.N, Ktot = a.Ktot;
-
-  // per-lane validity of (tap, row tile): bit tap*MT + mt
-  unsigned vmask = 0;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int64_t p = p0 + wave * WM + mt * 32 + li;
-    const bool in = p < M;
-    const int r = (int)((in ? p : 0) % HW);
-    const int oy = r / Wd, ox = r % Wd;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      const bool ok = in && (unsigned)(oy + dy - 1) < (unsigned)a.H && (unsigned)(ox + dx - 1) < (unsigned)Wd;
-      vmask |= (ok ? 1u : 0u) << (tap * MT + mt);
-    }
-  }
+  unsigned vmask = 0;                                            // per-lane validity bits, filled in after the first DMA ops
 
   // ---- unit order of this z-slice: all 16-channel units of 3x3 segments, then those of 1x1 segments.
   // The segment table is read from the kernel arguments ONCE, into scalars (a scalar load inside the
@@ -1083,6 +1068,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
     nx1 = unit_info(zs + nz);
     const unsigned sl = slane_of(nx1);
     for (int j = 0; j < (nx1.one ? OPS1 : OPS3); ++j) issue_op(nx1, sl, 1, j);
+  }
+
+  // per-lane validity of (tap, row tile): bit tap*MT + mt.  (After the first DMA ops are in flight; 32-bit arithmetic:
+  // the host checks B*H*W < 2^31.)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t p = p0 + wave * WM + mt * 32 + li;
+    const bool in = p < M;
+    const unsigned r = (unsigned)(in ? p : 0) % (unsigned)HW;
+    const int oy = (int)(r / (unsigned)Wd), ox = (int)(r % (unsigned)Wd);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const bool ok = in && (unsigned)(oy + dy - 1) < (unsigned)a.H && (unsigned)(ox + dx - 1) < (unsigned)Wd;
+      vmask |= (ok ? 1u : 0u) << (tap * MT + mt);
+    }
   }
 
   int buf = 0, k = 0;
@@ -1742,6 +1743,7 @@ extern "C" int ctdd_unet_conv_ring(const void* args_, int bnt, void* stream) {
   CTDD_REQUIRE(k == a.Ktot, CTDD_EINVAL, "Ktot=%d but segments sum to %d", a.Ktot, k);
   CTDD_REQUIRE(a.Ktot % 8 == 0 && a.N % 32 == 0 && a.N >= 32, CTDD_EINVAL, "ring conv: Ktot=%d N=%d (need Ktot %% 8 == 0, N %% 32 == 0)", a.Ktot, a.N);
   CTDD_REQUIRE((int64_t)a.Ktot * 64 < (int64_t)1 << 31, CTDD_ERANGE, "ring conv: Ktot=%d too large for 32-bit lane offsets", a.Ktot);
+  CTDD_REQUIRE((int64_t)a.B * a.H * a.W < (int64_t)1 << 31, CTDD_ERANGE, "ring conv: B*H*W does not fit 31 bits");
   CTDD_REQUIRE(a.ksplit <= 1 || (a.acc_buf && a.logits_C == 0), CTDD_EINVAL, "split-K needs acc_buf");
   hipStream_t st = (hipStream_t)stream;
   switch (bnt) {                            // bnt + 10: 256-pixel tiles, four waves, two workgroups per CU, ring of two
