@@ -102,6 +102,8 @@ struct HollowAttnArgs {
 // wave-uniform (broadcast) float4s, so the inner loop is 2 HD FMAs per key against HD/2 LDS reads.
 // Keys are consumed four at a time: one running-max update and five exps per four keys.
 constexpr int AQ = 128, AK = 32;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ inline f32x2 pk_fma(f32x2 x, f32x2 y, f32x2 z) { return __builtin_elementwise_fma(x, y, z); }   // v_pk_fma_f32
 template <int HD>
 __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[AK * HD];
@@ -109,15 +111,16 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AQ;
   const int i = i0 + threadIdx.x;
   const bool qok = i < a.Tq;
-  float qv[HD], acc[HD];
+  f32x2 qv[HD / 2], acc[HD / 2];                                // pairs of head dimensions: packed fp32 FMA
 #pragma unroll
-  for (int c = 0; c < HD; ++c) { acc[c] = 0.0f; qv[c] = 0.0f; }
+  for (int c = 0; c < HD / 2; ++c) { acc[c] = f32x2{0.0f, 0.0f}; qv[c] = f32x2{0.0f, 0.0f}; }
   if (qok) {
     const float* qr = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
       const float4 u = *(const float4*)(qr + c);
-      qv[c] = u.x * a.scale; qv[c + 1] = u.y * a.scale; qv[c + 2] = u.z * a.scale; qv[c + 3] = u.w * a.scale;
+      qv[c / 2] = f32x2{u.x * a.scale, u.y * a.scale};
+      qv[c / 2 + 1] = f32x2{u.z * a.scale, u.w * a.scale};
     }
   }
   float m = -INFINITY, l = 0.0f;
@@ -152,13 +155,15 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
       float s[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float d = 0.0f;
+        f32x2 d2 = {0.0f, 0.0f};
         const float* kr = Ks + (jj + u) * HD;                  // (rows past nj hold zeros or stale keys: masked below)
 #pragma unroll
         for (int c = 0; c < HD; c += 4) {
           const float4 kv = *(const float4*)(kr + c);
-          d = fmaf(qv[c], kv.x, d); d = fmaf(qv[c + 1], kv.y, d); d = fmaf(qv[c + 2], kv.z, d); d = fmaf(qv[c + 3], kv.w, d);
+          d2 = pk_fma(qv[c / 2], f32x2{kv.x, kv.y}, d2);
+          d2 = pk_fma(qv[c / 2 + 1], f32x2{kv.z, kv.w}, d2);
         }
+        const float d = d2.x + d2.y;
         s[u] = (jj + u < nj && allowed(j0 + jj + u)) ? d : -INFINITY;
       }
       const float mn = fmaxf(fmaxf(m, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
@@ -168,16 +173,18 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
 #pragma unroll
       for (int u = 0; u < 4; ++u) p[u] = expf(s[u] - mn);       // exp(-inf) = 0 for masked keys
       l = l * corr + ((p[0] + p[1]) + (p[2] + p[3]));
+      const f32x2 corr2 = {corr, corr};
 #pragma unroll
-      for (int c = 0; c < HD; ++c) acc[c] *= corr;
+      for (int c = 0; c < HD / 2; ++c) acc[c] *= corr2;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float* vr = Vs + (jj + u) * HD;
+        const f32x2 p2 = {p[u], p[u]};
 #pragma unroll
         for (int c = 0; c < HD; c += 4) {
           const float4 vv = *(const float4*)(vr + c);
-          acc[c] = fmaf(p[u], vv.x, acc[c]); acc[c + 1] = fmaf(p[u], vv.y, acc[c + 1]);
-          acc[c + 2] = fmaf(p[u], vv.z, acc[c + 2]); acc[c + 3] = fmaf(p[u], vv.w, acc[c + 3]);
+          acc[c / 2] = pk_fma(p2, f32x2{vv.x, vv.y}, acc[c / 2]);
+          acc[c / 2 + 1] = pk_fma(p2, f32x2{vv.z, vv.w}, acc[c / 2 + 1]);
         }
       }
       m = mn;
@@ -187,7 +194,8 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
     const float inv = 1.0f / l;
     float* o = a.out + ((size_t)b * a.Tq + i) * a.out_rs + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; c += 4) *(float4*)(o + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
+    for (int c = 0; c < HD; c += 4)
+      *(float4*)(o + c) = make_float4(acc[c / 2].x * inv, acc[c / 2].y * inv, acc[c / 2 + 1].x * inv, acc[c / 2 + 1].y * inv);
   }
 }
 
