@@ -13,6 +13,13 @@
 
 namespace ctdd {
 
+__device__ inline unsigned short hk_bf16(float a) {            // round-to-nearest-even, as the hardware conversion
+  using v2f = __attribute__((ext_vector_type(2))) float;
+  using v2b = __attribute__((ext_vector_type(2))) __bf16;
+  v2f v = {a, 0.0f};
+  return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b)) & 0xFFFFu);
+}
+
 // ------------------------------------------------------------------ embedding (hollow_networks.py:729-753, 534-563)
 struct HollowEmbedArgs {
   const int64_t* x64; const int32_t* x32;       // (B, D) states
@@ -53,6 +60,7 @@ struct HollowLnArgs {
   const float* film; int film_stride;             // optional (B, 2E): out = a * LN + b, a = film[b][0:E], b = film[b][E:2E]
   int B, T, E;
   float* out;
+  unsigned short* out_hi; int64_t out_hi_bs;      // optional bf16 copy (GEMM operand in the bf16 mode)
 };
 __global__ __launch_bounds__(256) void k_hollow_layernorm(const HollowLnArgs a) {
   const int lane = threadIdx.x & 63;
@@ -67,25 +75,36 @@ __global__ __launch_bounds__(256) void k_hollow_layernorm(const HollowLnArgs a) 
   float q = 0.0f;
   for (int e = lane; e < E; e += 64) { const float d = x[e] + (y ? y[e] : 0.0f) - mean; q = fmaf(d, d, q); }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + a.eps);
-  float* o = a.out + (size_t)b * a.out_bs + (size_t)j * E;
+  float* o = a.out ? a.out + (size_t)b * a.out_bs + (size_t)j * E : nullptr;
+  unsigned short* oh = a.out_hi ? a.out_hi + (size_t)b * a.out_hi_bs + (size_t)j * E : nullptr;
   for (int e = lane; e < E; e += 64) {
     float v = (x[e] + (y ? y[e] : 0.0f) - mean) * rstd * a.gamma[e] + a.beta[e];
     if (a.film) v = a.film[(size_t)b * a.film_stride + e] * v + a.film[(size_t)b * a.film_stride + E + e];
-    o[e] = v;
+    if (o) o[e] = v;
+    if (oh) oh[e] = hk_bf16(v);
   }
 }
 
 // out[b][j][:] = p[b][j][:] + q[b][j][:], strided batches
 __global__ __launch_bounds__(256) void k_hollow_add(const float* __restrict__ p, int64_t p_bs, const float* __restrict__ q, int64_t q_bs,
-                                                   float* __restrict__ out, int64_t out_bs, int64_t per_batch) {
+                                                   float* __restrict__ out, unsigned short* __restrict__ out_hi, int64_t out_bs,
+                                                   int64_t per_batch) {
   const int b = blockIdx.y;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_batch; i += (int64_t)gridDim.x * 256)
-    out[(size_t)b * out_bs + i] = p[(size_t)b * p_bs + i] + q[(size_t)b * q_bs + i];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_batch; i += (int64_t)gridDim.x * 256) {
+    const float v = p[(size_t)b * p_bs + i] + q[(size_t)b * q_bs + i];
+    if (out) out[(size_t)b * out_bs + i] = v;
+    if (out_hi) out_hi[(size_t)b * out_bs + i] = hk_bf16(v);
+  }
 }
 // rows of a (B, E) matrix into slot 0 of a (B, T, E) buffer
-__global__ __launch_bounds__(256) void k_hollow_put_rows(const float* __restrict__ src, float* __restrict__ dst, int64_t dst_bs, int E) {
+__global__ __launch_bounds__(256) void k_hollow_put_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                        unsigned short* __restrict__ dst_hi, int64_t dst_bs, int E) {
   const int b = blockIdx.x;
-  for (int e = threadIdx.x; e < E; e += 256) dst[(size_t)b * dst_bs + e] = src[(size_t)b * E + e];
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const float v = src[(size_t)b * E + e];
+    if (dst) dst[(size_t)b * dst_bs + e] = v;
+    if (dst_hi) dst_hi[(size_t)b * dst_bs + e] = hk_bf16(v);
+  }
 }
 
 // ------------------------------------------------------------------ masked attention, online softmax
@@ -96,6 +115,7 @@ struct HollowAttnArgs {
   int64_t q_bs, k_bs, v_bs; int q_rs, k_rs, v_rs;
   int B, Tq, Tk, H, hd, mode; float scale;
   float* out; int out_rs;
+  unsigned short* out_hi;                        // optional bf16 copy, same row stride
 };
 // One thread = one query with the whole head dimension in registers (q[HD], acc[HD]); a workgroup = 128
 // consecutive queries of one (b, head); keys / values come through LDS in chunks of 32 and are read as
@@ -192,10 +212,16 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
   }
   if (qok) {
     const float inv = 1.0f / l;
-    float* o = a.out + ((size_t)b * a.Tq + i) * a.out_rs + h * HD;
+    const size_t oo = ((size_t)b * a.Tq + i) * a.out_rs + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; c += 4)
-      *(float4*)(o + c) = make_float4(acc[c / 2].x * inv, acc[c / 2].y * inv, acc[c / 2 + 1].x * inv, acc[c / 2 + 1].y * inv);
+    for (int c = 0; c < HD; c += 4) {
+      const float4 v = make_float4(acc[c / 2].x * inv, acc[c / 2].y * inv, acc[c / 2 + 1].x * inv, acc[c / 2 + 1].y * inv);
+      if (a.out) *(float4*)(a.out + oo + c) = v;
+      if (a.out_hi) {
+        unsigned short* oh = a.out_hi + oo + c;
+        oh[0] = hk_bf16(v.x); oh[1] = hk_bf16(v.y); oh[2] = hk_bf16(v.z); oh[3] = hk_bf16(v.w);
+      }
+    }
   }
 }
 
@@ -214,30 +240,31 @@ extern "C" int ctdd_hollow_embed(const void* args_, void* stream) {
 
 extern "C" int ctdd_hollow_layernorm(const void* args_, void* stream) {
   const HollowLnArgs& a = *(const HollowLnArgs*)args_;
-  CTDD_REQUIRE(a.x && a.gamma && a.beta && a.out && a.B > 0 && a.T > 0 && a.E > 0, CTDD_EINVAL, "hollow layernorm: bad arguments");
+  CTDD_REQUIRE(a.x && a.gamma && a.beta && (a.out || a.out_hi) && a.B > 0 && a.T > 0 && a.E > 0, CTDD_EINVAL, "hollow layernorm: bad arguments");
   const int64_t rows = (int64_t)a.B * a.T;
   hipLaunchKernelGGL(k_hollow_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return finish_launch("k_hollow_layernorm");
 }
 
-extern "C" int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, int64_t out_bs, int B,
-                               int64_t per_batch, void* stream) {
-  CTDD_REQUIRE(p && q && out && B > 0 && per_batch > 0, CTDD_EINVAL, "hollow add: bad arguments");
+extern "C" int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, int64_t out_bs,
+                               int B, int64_t per_batch, void* stream) {
+  CTDD_REQUIRE(p && q && (out || out_bf16) && B > 0 && per_batch > 0, CTDD_EINVAL, "hollow add: bad arguments");
   int gx = (int)((per_batch + 2047) / 2048);
   gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-  hipLaunchKernelGGL(k_hollow_add, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, p, p_bs, q, q_bs, out, out_bs, per_batch);
+  hipLaunchKernelGGL(k_hollow_add, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, p, p_bs, q, q_bs, out, (unsigned short*)out_bf16, out_bs,
+                     per_batch);
   return finish_launch("k_hollow_add");
 }
 
-extern "C" int ctdd_hollow_put_rows(const float* src, float* dst, int64_t dst_bs, int B, int E, void* stream) {
-  CTDD_REQUIRE(src && dst && B > 0 && E > 0, CTDD_EINVAL, "hollow put_rows: bad arguments");
-  hipLaunchKernelGGL(k_hollow_put_rows, dim3(B), dim3(256), 0, (hipStream_t)stream, src, dst, dst_bs, E);
+extern "C" int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, int64_t dst_bs, int B, int E, void* stream) {
+  CTDD_REQUIRE(src && (dst || dst_bf16) && B > 0 && E > 0, CTDD_EINVAL, "hollow put_rows: bad arguments");
+  hipLaunchKernelGGL(k_hollow_put_rows, dim3(B), dim3(256), 0, (hipStream_t)stream, src, dst, (unsigned short*)dst_bf16, dst_bs, E);
   return finish_launch("k_hollow_put_rows");
 }
 
 extern "C" int ctdd_hollow_attention(const void* args_, void* stream) {
   const HollowAttnArgs& a = *(const HollowAttnArgs*)args_;
-  CTDD_REQUIRE(a.q && a.k && a.v && a.out, CTDD_EINVAL, "hollow attention: null buffer");
+  CTDD_REQUIRE(a.q && a.k && a.v && (a.out || a.out_hi), CTDD_EINVAL, "hollow attention: null buffer");
   CTDD_REQUIRE(a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || a.Tk == 2 * a.Tq + 1) && (a.mode == 2 || a.Tk == a.Tq), CTDD_EINVAL,
                "hollow attention: mode %d with Tq=%d Tk=%d", a.mode, a.Tq, a.Tk);
   CTDD_REQUIRE(a.q_rs % 4 == 0 && a.k_rs % 4 == 0 && a.v_rs % 4 == 0 && a.out_rs % 4 == 0 && a.q_bs % 4 == 0 && a.k_bs % 4 == 0 && a.v_bs % 4 == 0,

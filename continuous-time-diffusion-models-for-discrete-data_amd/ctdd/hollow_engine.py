@@ -10,8 +10,11 @@ records the forward as a flat list of pre-bound libctdd launches, replayed as on
   into the key buffer, l2r+r2l, Q / K / V GEMMs, readout attention, out GEMM (+residual), FiLM residual MLPs
   (GELU GEMMs, LayerNorm+FiLM), logits GEMM.
 
-All arithmetic is fp32 (GEMMs on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32): the network's
-bar is 1e-4 on the logits against the reference's golden outputs.
+precision = "fp32" (default): all arithmetic fp32, GEMMs on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 --
+                     the network's bar is 1e-4 on the logits against the reference's golden outputs.
+precision = "bf16":  the token-level GEMMs take bf16 operands (weights and the LayerNorm / attention / MLP outputs
+                     that feed them) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the residual streams,
+                     LayerNorm, softmax and the per-sample FiLM path stay fp32.  Throughput mode, looser bar.
 """
 import ctypes as C
 import math
@@ -31,13 +34,13 @@ class _EmbedArgs(C.Structure):
 
 class _LnArgs(C.Structure):
     _fields_ = [("x", _P), ("y", _P), ("x_bs", _I64), ("y_bs", _I64), ("out_bs", _I64), ("gamma", _P), ("beta", _P), ("eps", _F),
-                ("film", _P), ("film_stride", _I), ("B", _I), ("T", _I), ("E", _I), ("out", _P)]
+                ("film", _P), ("film_stride", _I), ("B", _I), ("T", _I), ("E", _I), ("out", _P), ("out_hi", _P), ("out_hi_bs", _I64)]
 
 
 class _AttnArgs(C.Structure):
     _fields_ = [("q", _P), ("k", _P), ("v", _P), ("q_bs", _I64), ("k_bs", _I64), ("v_bs", _I64), ("q_rs", _I), ("k_rs", _I),
                 ("v_rs", _I), ("B", _I), ("Tq", _I), ("Tk", _I), ("H", _I), ("hd", _I), ("mode", _I), ("scale", _F), ("out", _P),
-                ("out_rs", _I)]
+                ("out_rs", _I), ("out_hi", _P)]
 
 
 _sigs_done = False
@@ -48,8 +51,8 @@ def _lib():
     lib = _unet_lib()
     if not _sigs_done:
         for name, argt in (("ctdd_hollow_embed", [_P, _P]), ("ctdd_hollow_layernorm", [_P, _P]),
-                           ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _I64, _I, _I64, _P]),
-                           ("ctdd_hollow_put_rows", [_P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P])):
+                           ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _P, _I64, _I, _I64, _P]),
+                           ("ctdd_hollow_put_rows", [_P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P])):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -67,8 +70,12 @@ def supports(model):
 
 
 class HollowEngine:
-    def __init__(self, model):
+    def __init__(self, model, precision=None):
         self.model, self.net = model, model.net
+        self.precision = precision or getattr(model.net.config.model, "engine_precision", "fp32")
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"unknown engine precision {self.precision}")
+        self.fast = self.precision == "bf16"
         self.dev = next(self.net.parameters()).device
         if self.dev.type != "cuda":
             raise native.CtddError("HollowEngine needs the model on a GPU")
@@ -90,6 +97,8 @@ class HollowEngine:
         st.t_in = torch.zeros((B,), dtype=torch.float32, device=dev)
         stream = lambda: torch.cuda.current_stream().cuda_stream
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        fast = self.fast
+        hi = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev) if fast else None     # bf16 GEMM operands
 
         def P(t):
             return None if t is None else t.data_ptr()
@@ -107,35 +116,52 @@ class HollowEngine:
             run.label, run.flops = (fn.__name__, label), flops
             plan.append(run)
 
-        def linear(x, rows, K, lin_w, lin_b, out, act=0, res=None, label=""):
-            """out[rows][N] = act(x[rows][K] @ W^T + b) (+ res) on the fp32 implicit-GEMM kernel."""
+        def linear(x, rows, K, lin_w, lin_b, out, act=0, res=None, label="", x_hi=None, out_hi=None):
+            """out[rows][N] = act(x[rows][K] @ W^T + b) (+ res) on the implicit-GEMM kernel: fp32 operands, or bf16
+            operands (x_hi, bf16 weights) when x_hi is given; out (fp32) and/or out_hi (bf16) receive the result."""
             w = W(lin_w)
             N = w.shape[0]
             assert w.shape[1] == K and K % 16 == 0
             a = _ConvArgs()
             a.nseg = 1
-            a.seg[0].f32, a.seg[0].C, a.seg[0].kind = P(x), K, SEG_1x1
-            a.w_f32, a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = P(w), 1, rows, 1, rows, 1, N, K
+            a.seg[0].C, a.seg[0].kind = K, SEG_1x1
+            use_bf16 = x_hi is not None
+            if use_bf16:
+                wh = w.to(torch.bfloat16).contiguous()
+                keep.append(wh)
+                a.seg[0].hi, a.w_hi = P(x_hi), P(wh)
+            else:
+                a.seg[0].f32, a.w_f32 = P(x), P(w)
+            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = 1, rows, 1, rows, 1, N, K
             a.bias = P(W(lin_b)) if lin_b is not None else None
             a.res_f32 = P(res)
-            a.out_f32, a.act = P(out), act
+            a.out_f32, a.out_hi, a.act = P(out), P(out_hi), act
             keep.append(a)
-            bk = 32 if K % 32 == 0 else 16
-            bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
-            launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, 1, label=f"linear {label} {rows}x{K}->{N}", flops=2 * rows * K * N)
+            if use_bf16:
+                bk = 96 if K % 96 == 0 else 64 if K % 64 == 0 else 32 if K % 32 == 0 else 16
+                bnt = 1 if bk == 16 else (3 if (N % 96 == 0 and bk in (96, 32)) else 4 if N % 128 == 0 else 2 if (N % 64 == 0 and bk == 64) else 1)
+                if (bk, bnt) not in ((96, 3), (96, 4), (96, 1), (64, 4), (64, 2), (64, 1), (32, 1), (32, 3), (32, 4), (16, 1)):
+                    bnt = 1
+            else:
+                bk = 32 if K % 32 == 0 else 16
+                bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
+            launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, 0 if use_bf16 else 1, label=f"linear {label} {rows}x{K}->{N}",
+                   flops=2 * rows * K * N)
 
-        def layernorm(x, x_bs, T, Ed, norm, out, out_bs, y=None, y_bs=0, film=None, film_stride=0):
+        def layernorm(x, x_bs, T, Ed, norm, out, out_bs, y=None, y_bs=0, film=None, film_stride=0, out_hi=None, out_hi_bs=0):
             a = _LnArgs()
             a.x, a.y, a.x_bs, a.y_bs, a.out_bs = P(x), P(y), x_bs, y_bs, out_bs
             a.gamma, a.beta, a.eps = P(W(norm.weight)), P(W(norm.bias)), float(norm.eps)
             a.film, a.film_stride, a.B, a.T, a.E, a.out = P(film), film_stride, B, T, Ed, P(out)
+            a.out_hi, a.out_hi_bs = P(out_hi), out_hi_bs
             keep.append(a)
             launch(lib.ctdd_hollow_layernorm, C.byref(a))
 
-        def attention(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, Tq, Tk, mode, out):
+        def attention(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, Tq, Tk, mode, out, out_hi=None):
             a = _AttnArgs()
             a.q, a.k, a.v, a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = q, k, v, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs
             a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale, a.out, a.out_rs = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd), P(out), E
+            a.out_hi = P(out_hi)
             keep.append(a)
             launch(lib.ctdd_hollow_attention, C.byref(a), label=f"attention mode {mode} {Tq}x{Tk}")
 
@@ -156,41 +182,43 @@ class HollowEngine:
         launch(lib.ctdd_hollow_embed, C.byref(ea))
 
         # ---- the two causal stacks
-        ln_buf, qkv, ctx, hid = f32(R, E), f32(R, 3 * E), f32(R, E), f32(R, mlp)
-        keep.extend([ln_buf, qkv, ctx, hid])
+        ln_buf, qkv, ctx, hid = (None if fast else f32(R, E)), f32(R, 3 * E), (None if fast else f32(R, E)), (None if fast else f32(R, mlp))
+        ln_hi, ctx_hi, hid_hi = hi(R, E), hi(R, E), hi(R, mlp)
+        keep.extend([ln_buf, qkv, ctx, hid, ln_hi, ctx_hi, hid_hi])
         for x, stack, mode in ((st.l2r, net.module_l2r, 0), (st.r2l, net.module_r2l, 1)):
             for blk in stack.trans_block_layers:
                 sa, ff = blk.self_attention_block, blk.feed_forward_block
                 mha = sa.self_attention
-                layernorm(x, D * E, D, E, sa.norm, ln_buf, D * E)
-                linear(ln_buf, R, E, mha.in_proj_weight, mha.in_proj_bias, qkv, label="qkv")
-                attention(P(qkv), D * 3 * E, 3 * E, P(qkv) + 4 * E, D * 3 * E, 3 * E, P(qkv) + 8 * E, D * 3 * E, 3 * E, D, D, mode, ctx)
-                linear(ctx, R, E, mha.out_proj.weight, mha.out_proj.bias, x, res=x, label="attn out")     # in place: + inputs
-                layernorm(x, D * E, D, E, ff.norm, ln_buf, D * E)
-                linear(ln_buf, R, E, ff.mlp.fc1.weight, ff.mlp.fc1.bias, hid, act=1, label="fc1")
-                linear(hid, R, mlp, ff.mlp.fc2.weight, None, x, res=x, label="fc2")
+                layernorm(x, D * E, D, E, sa.norm, ln_buf, D * E, out_hi=ln_hi, out_hi_bs=D * E)
+                linear(ln_buf, R, E, mha.in_proj_weight, mha.in_proj_bias, qkv, label="qkv", x_hi=ln_hi)
+                attention(P(qkv), D * 3 * E, 3 * E, P(qkv) + 4 * E, D * 3 * E, 3 * E, P(qkv) + 8 * E, D * 3 * E, 3 * E, D, D, mode, ctx,
+                          out_hi=ctx_hi)
+                linear(ctx, R, E, mha.out_proj.weight, mha.out_proj.bias, x, res=x, label="attn out", x_hi=ctx_hi)   # in place: + inputs
+                layernorm(x, D * E, D, E, ff.norm, ln_buf, D * E, out_hi=ln_hi, out_hi_bs=D * E)
+                linear(ln_buf, R, E, ff.mlp.fc1.weight, ff.mlp.fc1.bias, hid, act=1, label="fc1", x_hi=ln_hi, out_hi=hid_hi)
+                linear(hid, R, mlp, ff.mlp.fc2.weight, None, x, res=x, label="fc2", x_hi=hid_hi)
 
         # ---- attention readout
         ro = net.readout_module
         ca = ro.cross_attention
         Tk = 2 * D + 1
-        allk = f32(B, Tk, E)
-        keep.append(allk)
-        launch(lib.ctdd_hollow_put_rows, P(st.temb), P(allk), Tk * E, B, E)
-        layernorm(st.l2r, D * E, D, E, ro.ln1, allk[:, 1:], Tk * E)
-        layernorm(st.r2l, D * E, D, E, ro.ln2, allk[:, D + 1:], Tk * E)
-        qin, raw = f32(R, E), f32(R, E)
-        launch(lib.ctdd_hollow_add, P(allk) + 4 * E, Tk * E, P(allk) + 4 * (D + 1) * E, Tk * E, P(qin), D * E, B, D * E)
-        launch(lib.ctdd_hollow_add, P(st.l2r), D * E, P(st.r2l), D * E, P(raw), D * E, B, D * E)
+        allk, allk_hi = f32(B, Tk, E), hi(B, Tk, E)
+        keep.extend([allk, allk_hi])
+        launch(lib.ctdd_hollow_put_rows, P(st.temb), P(allk), P(allk_hi), Tk * E, B, E)
+        layernorm(st.l2r, D * E, D, E, ro.ln1, allk[:, 1:], Tk * E, out_hi=None if not fast else allk_hi[:, 1:], out_hi_bs=Tk * E)
+        layernorm(st.r2l, D * E, D, E, ro.ln2, allk[:, D + 1:], Tk * E, out_hi=None if not fast else allk_hi[:, D + 1:], out_hi_bs=Tk * E)
+        qin, qin_hi, raw = (None if fast else f32(R, E)), hi(R, E), f32(R, E)
+        launch(lib.ctdd_hollow_add, P(allk) + 4 * E, Tk * E, P(allk) + 4 * (D + 1) * E, Tk * E, P(qin), P(qin_hi), D * E, B, D * E)
+        launch(lib.ctdd_hollow_add, P(st.l2r), D * E, P(st.r2l), D * E, P(raw), None, D * E, B, D * E)
         qb, kb, vb = f32(R, E), f32(B * Tk, E), f32(B * Tk, E)
-        keep.extend([qin, raw, qb, kb, vb])
-        linear(qin, R, E, ca.dense_query.weight, None, qb, label="readout q")
-        linear(allk, B * Tk, E, ca.dense_key.weight, ca.dense_key.bias, kb, label="readout k")
-        linear(allk, B * Tk, E, ca.dense_val.weight, ca.dense_val.bias, vb, label="readout v")
-        attention(P(qb), D * E, E, P(kb), Tk * E, E, P(vb), Tk * E, E, D, Tk, 2, ctx)
-        xr = f32(R, E)
-        keep.append(xr)
-        linear(ctx, R, E, ca.out_linear.weight, ca.out_linear.bias, xr, res=raw, label="readout out")
+        keep.extend([qin, qin_hi, raw, qb, kb, vb])
+        linear(qin, R, E, ca.dense_query.weight, None, qb, label="readout q", x_hi=qin_hi)
+        linear(allk, B * Tk, E, ca.dense_key.weight, ca.dense_key.bias, kb, label="readout k", x_hi=allk_hi)
+        linear(allk, B * Tk, E, ca.dense_val.weight, ca.dense_val.bias, vb, label="readout v", x_hi=allk_hi)
+        attention(P(qb), D * E, E, P(kb), Tk * E, E, P(vb), Tk * E, E, D, Tk, 2, ctx, out_hi=ctx_hi)
+        xr, xr_hi = (None if fast else f32(R, E)), hi(R, E)
+        keep.extend([xr, xr_hi])
+        linear(ctx, R, E, ca.out_linear.weight, ca.out_linear.bias, xr, res=raw, label="readout out", x_hi=ctx_hi, out_hi=xr_hi)
 
         # ---- FiLM residual readout
         rr = ro.model
@@ -199,20 +227,21 @@ class HollowEngine:
         lin = [l for l in rr.mlp.layers if isinstance(l, torch.nn.Linear)]
         linear(st.temb, B, E, lin[0].weight, lin[0].bias, tm_h, act=2, label="temb mlp 1")
         linear(tm_h, B, mlp, lin[1].weight, lin[1].bias, tm, label="temb mlp 2")
-        h, r, rh, film = f32(R, E2), f32(R, E2), f32(R, mlp), f32(B, 4 * E)
-        keep.extend([tm_h, tm, h, r, rh, film])
-        linear(xr, R, E, rr.input_layer.weight, rr.input_layer.bias, h, label="readout in")
+        h, r, rh = f32(R, E2), f32(R, E2), (None if fast else f32(R, mlp))
+        h_hi, rh_hi = hi(R, E2), hi(R, mlp)
+        keep.extend([tm_h, tm, h, r, rh, h_hi, rh_hi])
+        linear(xr, R, E, rr.input_layer.weight, rr.input_layer.bias, h, label="readout in", x_hi=xr_hi, out_hi=h_hi)
         for i in range(rr.n_res):
             mlp_i, ln_i = rr.resid_layers[2 * i], rr.resid_layers[2 * i + 1]
             li = [l for l in mlp_i.layers if isinstance(l, torch.nn.Linear)]
-            linear(h, R, E2, li[0].weight, li[0].bias, rh, act=2, label="resid 1")
-            linear(rh, R, mlp, li[1].weight, li[1].bias, r, label="resid 2")
+            linear(h, R, E2, li[0].weight, li[0].bias, rh, act=2, label="resid 1", x_hi=h_hi, out_hi=rh_hi)
+            linear(rh, R, mlp, li[1].weight, li[1].bias, r, label="resid 2", x_hi=rh_hi)
             fl = f32(B, 4 * E)
             keep.append(fl)
-            linear(tm, B, 4 * E, rr.film_layer[i].weight, rr.film_layer[i].bias, fl, label="film")
-            layernorm(h, D * E2, D, E2, ln_i, h, D * E2, y=r, y_bs=D * E2, film=fl, film_stride=4 * E)
+            linear(tm, B, 4 * E, rr.film_layer[i].weight, rr.film_layer[i].bias, fl, label="film")          # per-sample path: fp32
+            layernorm(h, D * E2, D, E2, ln_i, h, D * E2, y=r, y_bs=D * E2, film=fl, film_stride=4 * E, out_hi=h_hi, out_hi_bs=D * E2)
         st.logits = f32(B, D, rr.out_dim)
-        linear(h, R, E2, rr.logits_layer.weight, rr.logits_layer.bias, st.logits, label="logits")
+        linear(h, R, E2, rr.logits_layer.weight, rr.logits_layer.bias, st.logits, label="logits", x_hi=h_hi)
         st.plan, st.keep, st.graph = plan, keep, None
         return st
 

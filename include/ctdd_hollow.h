@@ -25,12 +25,13 @@ int ctdd_hollow_embed(const void* embed_args, void* stream);
 typedef struct {
   const float* x; const float* y; int64_t x_bs, y_bs, out_bs; const float* gamma; const float* beta; float eps;
   const float* film; int film_stride; int B, T, E; float* out;
+  void* out_bf16; int64_t out_bf16_bs;            /* optional bf16 copy of the output (GEMM operand of the bf16 mode) */
 } ctdd_hollow_ln_args;
 int ctdd_hollow_layernorm(const void* ln_args, void* stream);
 
-int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, int64_t out_bs, int B,
-                    int64_t per_batch, void* stream);                                   /* l2r + r2l */
-int ctdd_hollow_put_rows(const float* src, float* dst, int64_t dst_bs, int B, int E, void* stream);   /* temb into key slot 0 */
+int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, int64_t out_bs, int B,
+                    int64_t per_batch, void* stream);                                   /* l2r + r2l (fp32 and/or bf16 result) */
+int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, int64_t dst_bs, int B, int E, void* stream);   /* temb into key slot 0 */
 
 /* masked multi-head attention, softmax(scale q.k) v: mode 0 causal (j <= i, UniDirectionalTransformer l2r 534-560),
  * 1 anti-causal (j >= i, r2l), 2 readout over [temb | l2r | r2l] with Tk = 2 Tq + 1 (CrossAttention 204-280).
@@ -38,6 +39,7 @@ int ctdd_hollow_put_rows(const float* src, float* dst, int64_t dst_bs, int B, in
 typedef struct {
   const float* q; const float* k; const float* v; int64_t q_bs, k_bs, v_bs; int q_rs, k_rs, v_rs;
   int B, Tq, Tk, H, hd, mode; float scale; float* out; int out_rs;
+  void* out_bf16;                                 /* optional bf16 copy of the output */
 } ctdd_hollow_attn_args;
 int ctdd_hollow_attention(const void* attn_args, void* stream);
 

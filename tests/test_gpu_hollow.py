@@ -63,6 +63,9 @@ def test_hollow_engine_matches_module_maze():
         cfg.model.engine = "torch"
         ref = model(x, t).cpu()
         out = HollowEngine(model)(x, t).cpu()
+        fast = HollowEngine(model, precision="bf16")(x, t).cpu()
     assert ref.shape == out.shape == (5, 225, 3)
     assert (out - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0)
+    # bf16 GEMM operands (throughput mode): reported separately, looser bar
+    assert (fast - ref).abs().max().item() < 5e-2 * max(ref.abs().max().item(), 1.0)
     model.train()
