@@ -181,6 +181,16 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
 #endif
   constexpr int BN = 32 * BNT, LD = BN + 4, CH = BN / 8, RS = 64 / CH, STEPS = (32 + RS - 1) / RS;
   const int lane = threadIdx.x & 63, li = lane & 31, g = lane >> 5;
+  // The argument struct lives in the kernel-argument segment; left alone the compiler re-loads a field next to every use
+  // (260 scalar loads, each followed by a wait, in this unrolled epilogue).  Pin the integer fields in scalar registers.
+  auto pin32 = [](int v) { asm volatile("" : "+s"(v)); return v; };
+  const int aN = pin32(a.N), aB = pin32(a.B), a_tbs = pin32(a.tb_stride), a_lc = pin32(a.logits_C);
+  // (pointers stay as they are: laundering them through an integer loses the global address space -> flat_load/flat_store)
+  float* const p_out_f32 = a.out_f32;
+  unsigned short* const p_out_hi = a.out_hi;
+  const unsigned short* const p_res_bf16 = a.res_bf16;
+  const float* const p_res_f32 = a.res_f32;
+  const float* const p_tbias = a.tbias;
   if (a.ksplit > 1) {                                     // partial sums only; k_conv_finish does the rest
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -196,12 +206,12 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
   }
   const int cc = lane % CH, rsub = lane / CH;
   const int nc = n0 + cc * 8;                              // first of this lane's 8 columns
-  const bool lane_ok = rsub < RS && nc < a.N;              // (N is a multiple of 8)
+  const bool lane_ok = rsub < RS && nc < aN;              // (N is a multiple of 8)
   float bv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bv[j] = (a.bias && lane_ok) ? a.bias[nc + j] : 0.0f;
-  const int S = a.logits_C > 0 ? a.N / a.logits_C : 1;     // logits layout: 8 consecutive n stay inside one channel (S % 8 == 0)
-  const int lch = a.logits_C > 0 ? nc / S : 0, ls = a.logits_C > 0 ? nc % S : 0;
+  const int S = a_lc > 0 ? aN / a_lc : 1;     // logits layout: 8 consecutive n stay inside one channel (S % 8 == 0)
+  const int lch = a_lc > 0 ? nc / S : 0, ls = a_lc > 0 ? nc % S : 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int64_t base = wrow0 + mt * 32;
@@ -209,12 +219,12 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
     ESTAMP(e0)
     // residual pieces of this lane's rows: issued before the LDS passes so that their latency hides behind them
     uint4 rres[STEPS];
-    if (a.res_bf16) {
+    if (p_res_bf16) {
 #pragma unroll
       for (int step = 0; step < STEPS; ++step) {
         const int row = step * RS + rsub;
         const int64_t p = base + row;
-        rres[step] = (lane_ok && row < 32 && p < M) ? *(const uint4*)(a.res_bf16 + (size_t)p * a.N + nc) : make_uint4(0, 0, 0, 0);
+        rres[step] = (lane_ok && row < 32 && p < M) ? *(const uint4*)(p_res_bf16 + (size_t)p * aN + nc) : make_uint4(0, 0, 0, 0);
       }
     }
     // ---- phase 1: column-per-lane accumulators -> row-major fp32 image
@@ -229,8 +239,8 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
     float tb0[8], tb1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      tb0[j] = (a.tbias && lane_ok) ? a.tbias[(size_t)b_first * a.tb_stride + nc + j] : 0.0f;
-      tb1[j] = (a.tbias && lane_ok && b_first + 1 < a.B) ? a.tbias[(size_t)(b_first + 1) * a.tb_stride + nc + j] : 0.0f;
+      tb0[j] = (p_tbias && lane_ok) ? p_tbias[(size_t)b_first * a_tbs + nc + j] : 0.0f;
+      tb1[j] = (p_tbias && lane_ok && b_first + 1 < aB) ? p_tbias[(size_t)(b_first + 1) * a_tbs + nc + j] : 0.0f;
     }
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
@@ -242,8 +252,8 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bv[j] + (second ? tb1[j] : tb0[j]);
-        const size_t o = (size_t)p * a.N + nc;
-        if (a.res_bf16) {
+        const size_t o = (size_t)p * aN + nc;
+        if (p_res_bf16) {
           const uint4 rr = rres[step];
           const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
@@ -251,21 +261,21 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
             v[2 * j] += __uint_as_float(rw[j] << 16);
             v[2 * j + 1] += __uint_as_float(rw[j] & 0xFFFF0000u);
           }
-        } else if (a.res_f32) {
-          const float4 r0 = *(const float4*)(a.res_f32 + o), r1 = *(const float4*)(a.res_f32 + o + 4);
+        } else if (p_res_f32) {
+          const float4 r0 = *(const float4*)(p_res_f32 + o), r1 = *(const float4*)(p_res_f32 + o + 4);
           v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
         }
-        if (a.out_f32) {
-          float* dst = a.out_f32 + o;
-          if (a.logits_C > 0) {
+        if (p_out_f32) {
+          float* dst = p_out_f32 + o;
+          if (a_lc > 0) {
             const int b = b_first + (second ? 1 : 0);
-            dst = a.out_f32 + (((size_t)b * a.logits_C + lch) * HW + (p - (int64_t)b * HW)) * S + ls;
+            dst = p_out_f32 + (((size_t)b * a_lc + lch) * HW + (p - (int64_t)b * HW)) * S + ls;
           }
           *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
-        if (a.out_hi)
-          *(uint4*)(a.out_hi + o) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+        if (p_out_hi)
+          *(uint4*)(p_out_hi + o) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
         if (ts.lds) {                                      // final values back into the image for the column pass
           *(float4*)(xt + row * LD + cc * 8) = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)(xt + row * LD + cc * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -282,7 +292,7 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
 #pragma unroll
       for (int c0 = 0; c0 < BN; c0 += 64) {
         const int c = c0 + lane;
-        if (c < BN && n0 + c < a.N) {
+        if (c < BN && n0 + c < aN) {
           double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
 #pragma unroll
           for (int r8 = 0; r8 < 32; r8 += 8) {             // eight independent LDS reads in flight; fp32 sums of eight rows, fp64 across blocks
