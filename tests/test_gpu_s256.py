@@ -103,3 +103,29 @@ def test_midpoint_base_and_ragged_tail(env):
     ref, decided = oph.tauleap_draw_replay(rr.numpy(), x.numpy(), h, False, 5, 1, x_base=xb.numpy())
     dec = torch.from_numpy(decided)
     assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 1e-2 and dec.float().mean() > 0.5
+
+
+def test_full_size_properties(env):
+    """BASELINE size (N=256, D=784, S=256): size-independent properties of the fused step -- determinism under a fixed
+    Philox key/offset, a different stream for a different offset, no move at h = 0, states stay in range, and the
+    change counter equals the number of moved dimensions."""
+    native, pr, _ = env
+    N, D = 256, 784
+    g = torch.Generator(device="cuda").manual_seed(3)
+    logits = torch.randn((N, D, S), generator=g, device="cuda") * 2.0
+    x = torch.randint(0, S, (N, D), generator=g, device="cuda", dtype=torch.int32)
+    tt = torch.tensor([0.4])
+    tabs = native.S256Tables(pr.transition(tt), pr.base_rate, 1e-9)
+    beta = float(pr.beta(tt)[0])
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    a = native.tauleap_step_s256(logits, x, tabs, 0, beta, 2e-3, native.STEP_ORDINAL, 7, 11, changed=cnt)
+    b = native.tauleap_step_s256(logits, x, tabs, 0, beta, 2e-3, native.STEP_ORDINAL, 7, 11)
+    c = native.tauleap_step_s256(logits, x, tabs, 0, beta, 2e-3, native.STEP_ORDINAL, 7, 12)
+    z = native.tauleap_step_s256(logits, x, tabs, 0, beta, 0.0, native.STEP_ORDINAL, 7, 11)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.equal(z, x)
+    assert int(a.min()) >= 0 and int(a.max()) <= S - 1
+    moved = int((a != x).sum())
+    assert int(cnt.item()) == moved and 0 < moved < N * D
+    # non-ordinal: a dimension with two or more jumps stays, so no more dimensions move than in the ordinal run with the same stream
+    d = native.tauleap_step_s256(logits, x, tabs, 0, beta, 2e-3, 0, 7, 11)
+    assert int((d != x).sum()) <= moved
