@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
+    ap.add_argument("--model-opt", action="append", default=[], help="integer engine option, key=value (tuning sweeps)")
     return ap.parse_args()
 
 
@@ -200,6 +201,9 @@ def main():
     cfg, model, sampler = build_model(dev)
     if a.engine_streams is not None:
         cfg.model.engine_streams = a.engine_streams
+    for kv in a.model_opt:                     # e.g. --model-opt ring_min_tiles=160
+        k_, v_ = kv.split("=")
+        setattr(cfg.model, k_, int(v_))
     sampler.seed = 42
     sampler.rank_stream = rank              # distinct Philox key per rank; no data-path collective
     K, W = a.steps, a.warmup

@@ -224,7 +224,7 @@ class UNetEngine:
                 # measured at batch 256 (MNIST net): the LDS-DMA ring wins where 512-pixel tiles give >= 160
                 # workgroups and every unit has nine taps (28x28, 14x14); the patch kernel (128/256-pixel tiles, two
                 # workgroups per CU) elsewhere.  Split-K lost everywhere it was tried (fp32 atomics + finish pass).
-                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= 160 and N % 96 == 0) else "patch"
+                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= int(getattr(m, "ring_min_tiles", 80)) and N % 96 == 0) else "patch"
             resident = which == "res" and patchable and all(c % 32 == 0 for c in cs) and N % 32 == 0
             ring = which == "ring" and patchable and all(c % 16 == 0 for c in cs) and N % 32 == 0
             if resident or ring:
@@ -254,7 +254,7 @@ class UNetEngine:
                     bk, bnt = 32, (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
                 else:
                     bk, bnt = 16, 1
-                wm = 64 if (bnt >= 2 and bk in (48, 64) and M_ >= 196 * 256 and (bk, bnt) != (64, 4)) else 32
+                wm = 64 if (bnt >= 2 and bk in (48, 64) and M_ >= int(getattr(m, "patch_wm64_min_rows", 196 * 128)) and (bk, bnt) != (64, 4)) else 32
                 units = sum(c // bk for c in cs)
                 if getattr(m, "conv_ksplit", 1) > 1 and units >= 2 and logits_C == 0 and out_f32_tensor is None:
                     a.ksplit = min(units, int(m.conv_ksplit))
