@@ -15,8 +15,9 @@ The JSON line also carries
                     (809 088 B at fp32) x batch / its mean launch duration (HIP events on
                     the launch stream); `mfma_view` prices the same launches by their matrix FLOPs
                     (3 split-bf16 products of the D x S x S contraction);
-  roofline_network  the score network's convolution launches (the larger share of the step):
-                    2 M N K matrix FLOPs / their summed launch durations vs the dense bf16 MFMA peak;
+  roofline_network  the score-network forward (the larger share of the step): 2 M N K matrix FLOPs of its convolutions /
+                    the forward's wall time as it runs in the loop (graph replay, two sub-batches on parallel streams, GroupNorm
+                    etc. included) vs the dense bf16 MFMA peak; the convolution launches replayed one by one are reported too;
   cpu_baseline      the CPU oracle (checker, never the product) running the same step on host cores.
 """
 import argparse
@@ -131,10 +132,23 @@ def network_roofline(model, batch):
             secs += e0.elapsed_time(e1) * 1e-3 / 3
             flops += step.flops
             n += 1
-    ach = flops / secs / 1e12
-    return {"kernel": "ctdd k_conv_ring / k_conv_patch / k_conv_igemm (bf16 implicit-GEMM convolutions of the score network)", "bound": "mfma",
-            "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5),
-            "traffic": None, "sub_batches": len(plans), "launches_per_forward": n, "sum_launch_us": round(secs * 1e6, 1), "matrix_gflop_per_forward": round(flops / 1e9, 1)}
+    seq = flops / secs / 1e12
+    # the forward as it runs in the timed loop (HIP-graph replay, sub-batches on parallel streams, all kernels of the network)
+    x = torch.randint(0, S, (batch, D), device=next(model.parameters()).device)
+    t = torch.full((batch,), 0.5, device=x.device)
+    model(x, t)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        model(x, t)
+    e1.record()
+    e1.synchronize()
+    fwd = e0.elapsed_time(e1) * 1e-3 / 10
+    ach = flops / fwd / 1e12
+    return {"kernel": "score-network forward: ctdd k_conv_ring / k_conv_patch / k_conv_igemm bf16 implicit-GEMM convolutions (+ GroupNorm, attention, time MLP)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5),
+            "traffic": None, "forward_ms": round(fwd * 1e3, 3), "matrix_gflop_per_forward": round(flops / 1e9, 1), "sub_batches": len(plans),
+            "conv_launches_per_forward": n, "conv_launches_sequential_tflops": round(seq, 2), "conv_launches_sequential_us": round(secs * 1e6, 1)}
 
 
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
