@@ -1555,29 +1555,44 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a) {
 
 // ------------------------------------------------------------------ logistic head (models.py:249-283)
 // mu = tanh(loc + x0), logits[s] = log(sigmoid(r) - sigmoid(l)) via log_minus_exp, straight into (B,D,S)
-struct LogisticArgs { const float* net; const float* x0; int B, C, HW, S, fix; float* out; };
+struct LogisticArgs { const float* net; const float* x0; int B, C, HW, S, fix; float* out; int fast; };
 __device__ inline float logsigmoidf(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+// hardware exp2 / log2 forms for the bf16 engine mode (~1e-6 relative; the mode's logits carry ~1e-2 already)
+__device__ inline float logsigmoid_fast(float x) { return fminf(x, 0.0f) - __logf(1.0f + __expf(-fabsf(x))); }
+// One wave per (b, c, pixel) row: mu and the inverse scale are computed once per row (the first version recomputed
+// tanh and exp for each of the S bins), lanes stride over the bins.
 __global__ __launch_bounds__(256) void k_logistic_head(const LogisticArgs a) {
   // net: NHWC [B][HW][2C] (loc channels 0..C-1, log_scale C..2C-1); x0: (B,C,HW) centred input
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)a.B * a.C * a.HW * a.S;
-  if (idx >= total) return;
-  const int s = (int)(idx % a.S);
-  const int64_t d = idx / a.S;                      // b*C*HW + c*HW + p
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // b*C*HW + c*HW + p
+  if (d >= (int64_t)a.B * a.C * a.HW) return;
   const int p = (int)(d % a.HW), c = (int)((d / a.HW) % a.C), b = (int)(d / ((int64_t)a.HW * a.C));
   const float* nr = a.net + ((size_t)b * a.HW + p) * 2 * a.C;
   const float mu = tanhf(nr[c] + a.x0[((size_t)b * a.C + c) * a.HW + p]);
   const float inv_scale = expf(-(nr[a.C + c] - 2.0f));
-  const float bw = 2.0f / (float)a.S;
-  const float centre = -1.0f + bw * 0.5f + (float)s * ((2.0f - bw) / (float)(a.S - 1));   // torch.linspace
-  const float l = (centre - bw * 0.5f - mu) * inv_scale, r = (centre + bw * 0.5f - mu) * inv_scale;
-  const float cl = logsigmoidf(l), cr = logsigmoidf(r);
-  float v = cr + log1pf(-expf(cl - cr) + 1e-6f);
-  if (a.fix) {
-    const float a2 = -l + cl, b2 = -r + cr;
-    v = fminf(v, a2 + log1pf(-expf(b2 - a2) + 1e-6f));
+  const float bw = 2.0f / (float)a.S, stepc = (2.0f - bw) / (float)(a.S - 1);
+  float* out = a.out + (size_t)d * a.S;
+  for (int s = lane; s < a.S; s += 64) {
+    const float centre = -1.0f + bw * 0.5f + (float)s * stepc;            // torch.linspace
+    const float l = (centre - bw * 0.5f - mu) * inv_scale, r = (centre + bw * 0.5f - mu) * inv_scale;
+    float v;
+    if (a.fast) {
+      const float cl = logsigmoid_fast(l), cr = logsigmoid_fast(r);
+      v = cr + __logf(1.0f - __expf(cl - cr) + 1e-6f);
+      if (a.fix) {
+        const float a2 = -l + cl, b2 = -r + cr;
+        v = fminf(v, a2 + __logf(1.0f - __expf(b2 - a2) + 1e-6f));
+      }
+    } else {
+      const float cl = logsigmoidf(l), cr = logsigmoidf(r);
+      v = cr + log1pf(-expf(cl - cr) + 1e-6f);
+      if (a.fix) {
+        const float a2 = -l + cl, b2 = -r + cr;
+        v = fminf(v, a2 + log1pf(-expf(b2 - a2) + 1e-6f));
+      }
+    }
+    out[s] = v;
   }
-  a.out[idx] = v;
 }
 
 }  // namespace ctdd
@@ -1843,7 +1858,7 @@ extern "C" int ctdd_unet_attention(const void* args_, void* stream) {
 
 extern "C" int ctdd_unet_logistic_head(const void* args_, void* stream) {
   const LogisticArgs& a = *(const LogisticArgs*)args_;
-  const int64_t total = (int64_t)a.B * a.C * a.HW * a.S;
-  hipLaunchKernelGGL(k_logistic_head, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const int64_t rows = (int64_t)a.B * a.C * a.HW;
+  hipLaunchKernelGGL(k_logistic_head, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return finish_launch("k_logistic_head");
 }

@@ -56,7 +56,7 @@ class _AttnArgs(C.Structure):
 
 
 class _LogisticArgs(C.Structure):
-    _fields_ = [("net", _P), ("x0", _P), ("B", _I), ("C", _I), ("HW", _I), ("S", _I), ("fix", _I), ("out", _P)]
+    _fields_ = [("net", _P), ("x0", _P), ("B", _I), ("C", _I), ("HW", _I), ("S", _I), ("fix", _I), ("out", _P), ("fast", _I)]
 
 
 _sigs_done = False
@@ -256,8 +256,11 @@ class UNetEngine:
                     bk, bnt = 16, 1
                 wm = 64 if (bnt >= 2 and bk in (48, 64) and M_ >= int(getattr(m, "patch_wm64_min_rows", 196 * 128)) and (bk, bnt) != (64, 4)) else 32
                 units = sum(c // bk for c in cs)
+                nwg = -(-M_ // (4 * wm)) * -(-N // (32 * bnt))
                 if getattr(m, "conv_ksplit", 1) > 1 and units >= 2 and logits_C == 0 and out_f32_tensor is None:
                     a.ksplit = min(units, int(m.conv_ksplit))
+                elif nwg <= int(getattr(m, "ksplit_max_wgs", 96)) and units >= 4 and logits_C == 0 and out_f32_tensor is None:
+                    a.ksplit = max(1, min(units // 2, 256 // nwg))       # tiny grids (4x4 levels): split K to fill the chip
                 if a.ksplit > 1:
                     zero_views.append((a, M_ * N))
                 launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm, label=lab + f" patch bk={bk} bnt={bnt} wm={wm} ks={a.ksplit}",
@@ -265,6 +268,8 @@ class UNetEngine:
             else:
                 bk = pick_bk(cs)
                 bnt = pick_bnt(N, bk)
+                if (not self.precise) and -(-M_ // 128) * -(-N // (32 * bnt)) < 64 and bk in (96, 64, 32):
+                    bnt = 1                                        # tiny grids: 32-column tiles, more workgroups
                 launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}", flops=2 * M_ * N * w2d.shape[1])
 
         def gn_apply(srcs, norm, swish, eps, HW):
@@ -422,6 +427,7 @@ class UNetEngine:
             la = _LogisticArgs()
             la.net, la.x0, la.B, la.C, la.HW, la.S, la.fix, la.out = (ptr(st.net_out), ptr(st.x0), B, Cin, H0 * W0, S,
                                                                      int(bool(m.fix_logistic)), ptr(st.logits))
+            la.fast = 0 if self.precise else 1
             keep.append(la)
             launch(lib.ctdd_unet_logistic_head, C.byref(la))
         else:

@@ -75,7 +75,8 @@ int ctdd_unet_time(const void* time_args, const float* proj_w, const float* proj
 typedef struct { const float* qkv; int B, T, C, heads; void* out_hi; float* out_f32; } ctdd_attn_args;
 int ctdd_unet_attention(const void* attn_args, void* stream);              /* unet.py:176-200 */
 
-typedef struct { const float* net; const float* x0; int B, C, HW, S, fix; float* out; } ctdd_logistic_args;
+typedef struct { const float* net; const float* x0; int B, C, HW, S, fix; float* out;
+                 int fast;   /* 1: hardware exp2/log2 forms (bf16 engine mode) */ } ctdd_logistic_args;
 int ctdd_unet_logistic_head(const void* logistic_args, void* stream);      /* models.py:249-283 */
 
 #ifdef __cplusplus
