@@ -10,10 +10,12 @@ constexpr int POISSON_ICDF_KMAX = 64;
 //   Lambda = h * sum_s r_s <= SUPERPOSE_MAX_LAMBDA:  K ~ Poisson(Lambda) from the first uniform(s) of the
 //     row's stream (Lambda > 12: sum of n = ceil(Lambda/12) draws of Poisson(Lambda/n), one uniform each),
 //     then K destinations ~ Categorical(r) by inverse CDF from the following uniforms;
-//   above: the same one level down -- every sub-block b of 4 consecutive destinations draws
-//     K_b ~ Poisson(h * sum_{s in b} r_s) from uniform (b & 3) of Philox block DENSE_DRAW0 + (b >> 2)
-//     and, if K_b > 0, K_b picks among its 4 destinations from the private stream PICK_DRAW0 + 16 b
-//     (K_b for a rate > 12 is the sum of <= 64 equal parts from the stream SPLIT_DRAW0 + 16 b).
+//   above: one level down -- sub-block b of 4 consecutive destinations with rate lam_b = h * sum_{s in b} r_s:
+//     lam_b <= 12: K_b ~ Poisson(lam_b) from uniform (b & 3) of Philox block DENSE_DRAW0 + (b >> 2) and, if K_b > 0,
+//       K_b picks among its 4 destinations from the private stream PICK_DRAW0 + 16 b;
+//     lam_b > 12: the reference's own form, one independent Poisson(h r_s) per destination from the stream
+//       SPLIT_DRAW0 + 16 b (inverse CDF up to 12, Hoermann's PTRS transformed rejection above: O(1) for any rate --
+//       random-init logistic heads produce h r_s ~ 1e6, where splitting or picking one jump at a time never ends).
 constexpr float SUPERPOSE_MAX_LAMBDA = 64.0f;
 constexpr uint32_t DENSE_DRAW0 = 1024u;
 constexpr uint32_t SPLIT_DRAW0 = 8192u;
@@ -52,21 +54,29 @@ struct PhiloxStream {
   }
 };
 
-// Poisson draw of one (sub-block) rate.  u = its uniform.  lam > 12 is split into n <= 64 equal
-// independent parts (a sum of Poissons is Poisson) drawn from the element's private stream; parts
-// that are still > 12 (lam > 768: every such draw saturates the state clamp) are taken at their
-// mean.  NaN / negative rates give 0 (the reference's torch.poisson raises there).
-__device__ inline int poisson_element(float lam, float u, uint64_t seed, uint64_t offset, uint64_t row, int s) {
+// Poisson(lam), lam > 12: PTRS (W. Hoermann, "The transformed rejection method for generating Poisson random
+// variables", 1993; the algorithm numpy and ATen use for large rates).  Two uniforms per trial, ~1.1-1.3 trials.
+// The acceptance test runs in fp64 (k log(lam) - lgamma(k+1) cancels ~1e7-sized terms at lam ~ 1e6).
+__device__ inline int poisson_ptrs(float lamf, PhiloxStream& rs) {
+  const double lam = (double)lamf, slam = sqrt(lam), loglam = log(lam);
+  const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+  const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+  for (int it = 0; it < 32; ++it) {
+    const double U = (double)rs.next() - 0.5, V = (double)rs.next();
+    const double us = 0.5 - fabs(U);
+    const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+    if (us >= 0.07 && V <= vr) return (int)fmin(kf, 1.0e9);
+    if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+    if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) return (int)fmin(kf, 1.0e9);
+  }
+  return (int)fmin(rint(lam), 1.0e9);                     // (32 rejections in a row: p < 1e-20)
+}
+
+// Sub-block count for lam <= 12 from its shared uniform; NaN / negative rates give 0 (torch.poisson raises there).
+__device__ inline int poisson_element(float lam, float u) {
   if (!(lam > 0.0f)) return 0;
   if (u + 2.0e-7f < 1.0f - lam) return 0;                 // u < 1-lam <= exp(-lam): certainly no jump
-  if (lam <= POISSON_ICDF_MAX_LAMBDA) return poisson_icdf(lam, u);
-  const int n = (int)fminf(ceilf(lam / POISSON_ICDF_MAX_LAMBDA), 64.0f);
-  const float lc = lam / (float)n;
-  if (!(lc <= POISSON_ICDF_MAX_LAMBDA)) return (int)fminf(rintf(lam), 1.0e9f);
-  PhiloxStream rs(seed, offset, row, SPLIT_DRAW0 + 16u * (uint32_t)s);   // s = sub-block index
-  int k = 0;
-  for (int i = 0; i < n; ++i) k += poisson_icdf(lc, rs.next());
-  return k;
+  return poisson_icdf(lam, u);
 }
 
 // K ~ Poisson(Lam), Lam <= SUPERPOSE_MAX_LAMBDA, from the row's stream (see the row rule above)
@@ -80,22 +90,40 @@ __device__ inline int poisson_row(float Lam, PhiloxStream& rng) {
 }
 
 // one sub-block of the dense regime: returns the number of jumps and adds sum_k (dest_k - base)
-// to *move.  r0..r3 = masked rates of destinations 4b..4b+3 (same units; `sh` turns them into
+// to *move (64-bit; the caller clamps the row total to +-S before the state update).  r0..r3 = masked rates of destinations 4b..4b+3 (same units; `sh` turns them into
 // rate*h), u = the sub-block's uniform.
 __device__ inline int subblock_draw(float r0, float r1, float r2, float r3, float sh, float u, uint64_t seed,
-                                    uint64_t offset, uint64_t row, int b, int base, int nvalid, int* move) {
+                                    uint64_t offset, uint64_t row, int b, int base, int nvalid, long long* move) {
   const float tot = (r0 + r1) + (r2 + r3);
-  const int K = poisson_element(sh * tot, u, seed, offset, row, b);
-  if (K > 0) {
-    PhiloxStream ps(seed, offset, row, PICK_DRAW0 + 16u * (uint32_t)b);
-    const float c0 = r0, c1 = r0 + r1, c2 = (r0 + r1) + r2;
-    for (int k = 0; k < K && k < 4096; ++k) {
-      const float v = ps.next() * tot;
-      int i = (v >= c0) + (v >= c1) + (v >= c2);
-      i = i < nvalid - 1 ? i : nvalid - 1;
-      *move += 4 * b + i - base;
+  const float lam = sh * tot;
+  if (!(lam > POISSON_ICDF_MAX_LAMBDA)) {
+    const int K = poisson_element(lam, u);
+    if (K > 0) {
+      PhiloxStream ps(seed, offset, row, PICK_DRAW0 + 16u * (uint32_t)b);
+      const float c0 = r0, c1 = r0 + r1, c2 = (r0 + r1) + r2;
+      for (int k = 0; k < K; ++k) {
+        const float v = ps.next() * tot;
+        int i = (v >= c0) + (v >= c1) + (v >= c2);
+        i = i < nvalid - 1 ? i : nvalid - 1;
+        *move += 4 * b + i - base;
+      }
     }
+    return K;
   }
+  // heavy sub-block: independent Poisson(h r_s) per destination (the reference's own draw)
+  PhiloxStream rs(seed, offset, row, SPLIT_DRAW0 + 16u * (uint32_t)b);
+  const float rr[4] = {r0, r1, r2, r3};
+  int K = 0;
+  long long mv = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float li = sh * rr[i];
+    if (i >= nvalid || !(li > 0.0f)) continue;
+    const int k = li <= POISSON_ICDF_MAX_LAMBDA ? poisson_icdf(li, rs.next()) : poisson_ptrs(li, rs);
+    K = (int)min((long long)K + k, (long long)1 << 30);
+    mv += (long long)k * (4 * b + i - base);
+  }
+  *move += mv;                                              // 64-bit: |k (s - x)| reaches 2.5e11 per destination
   return K;
 }
 

@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     // dense regime: per sub-block of 4 consecutive destinations (draw.hpp: subblock_draw).  The
     // lane owning destination 4b (element s = li + k*G with s % 4 == 0) gathers its three
     // neighbours by shuffle (G >= 4) or from its own slots (G < 4) and draws for the sub-block.
-    int cnt = 0, jl = 0;
+    int cnt = 0;
+    long long jl = 0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int s = li + k * G;
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
       }
     }
     cnt = grp_sum_i(cnt, G);
-    jl = grp_sum_i(jl, G);
-    jump = (ordinal || cnt <= 1) ? jl : 0;
+    for (int o = G >> 1; o >= 1; o >>= 1) jl += __shfl_xor(jl, o, WAVE);
+    jl = jl > S ? S : (jl < -S ? -S : jl);                    // |jump| >= S - 1 saturates the state clamp either way
+    jump = (ordinal || cnt <= 1) ? (int)jl : 0;
   }
   if (live && li == 0) {
     const int xn = min(max(xcur + jump, 0), S - 1);

@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
     // owns sub-blocks b = 8m + 2q + g.  Each lane builds Philox block 2m+g and trades it with its
     // partner, so both see blocks 2m and 2m+1 (uniform (b & 3) of block b >> 2).
     const float sh = scale * a.h;
-    int cnt = 0, jl = 0;
+    int cnt = 0;
+    long long jl = 0;
     for (int m = 0; m < 8; ++m) {
       const u4 mine = philox_row(a.seed, a.offset, rngrow, DENSE_DRAW0 + (uint32_t)(2 * m + g));
       u4 oth;
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
     }
     cnt += __shfl_xor(cnt, 32, WAVE);
     jl += __shfl_xor(jl, 32, WAVE);
-    jump = (ordinal || cnt <= 1) ? jl : 0;
+    jl = jl > S256 ? S256 : (jl < -S256 ? -S256 : jl);        // |jump| >= S - 1 saturates the state clamp either way
+    jump = (ordinal || cnt <= 1) ? (int)jl : 0;
   }
   STAMP(4)
 #ifdef CTDD_S256_STAMPS

@@ -94,6 +94,36 @@ def poisson_icdf(lam, u):
     return k, margin
 
 
+def poisson_ptrs(lam, uu):
+    """Hoermann's PTRS for Poisson(lam), lam > 12, exactly as csrc/draw.hpp:poisson_ptrs (fp64 arithmetic on the float32
+    uniforms taken from the iterator `uu`).  Returns (k, decided)."""
+    import math
+    lam = float(np.float32(lam))
+    slam, loglam = math.sqrt(lam), math.log(lam)
+    b = 0.931 + 2.53 * slam
+    a = -0.059 + 0.02483 * b
+    invalpha = 1.1239 + 1.1328 / (b - 3.4)
+    vr = 0.9277 - 3.6224 / (b - 2.0)
+    ok = True
+    for _ in range(32):
+        U = float(next(uu)) - 0.5
+        V = float(next(uu))
+        us = 0.5 - abs(U)
+        kf = math.floor((2.0 * a / us + b) * U + lam + 0.43)
+        ok &= abs(us - 0.07) > 1e-9 and abs(V - vr) > 1e-9
+        if us >= 0.07 and V <= vr:
+            return int(min(kf, 1.0e9)), ok
+        ok &= abs(us - 0.013) > 1e-9 and abs(V - us) > 1e-9
+        if kf < 0.0 or (us < 0.013 and V > us):
+            continue
+        lhs = math.log(V) + math.log(invalpha) - math.log(a / (us * us) + b)
+        rhs = -lam + kf * loglam - math.lgamma(kf + 1.0)
+        ok &= abs(lhs - rhs) > 1e-7 * max(1.0, abs(rhs))
+        if lhs <= rhs:
+            return int(min(kf, 1.0e9)), ok
+    return int(min(round(lam), 1.0e9)), ok
+
+
 def categorical_icdf(w, u):
     """First index s with cumsum(w)[s] > u*sum(w) (w >= 0, float32, row-wise).
     Returns (index, margin) where margin is the relative distance of the target to the nearest
@@ -197,21 +227,31 @@ def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
         margin = np.where(lam_b > 0, margin, 1.0)
         dd = np.ones(nd, dtype=bool)
         jl = np.zeros(nd, dtype=np.int64)
-        # rates above 12 are split into <= 64 equal parts from the sub-block's SPLIT stream
-        for ri, b in zip(*np.nonzero(lam_b > np.float32(POISSON_ICDF_MAX_LAMBDA))):
-            lam1 = lam_b[ri, b]
-            n = int(min(np.ceil(np.float32(lam1 / np.float32(POISSON_ICDF_MAX_LAMBDA))), 64.0))
-            lc = np.float32(lam1 / np.float32(n))
-            if not lc <= POISSON_ICDF_MAX_LAMBDA:
-                Kb[ri, b] = int(min(np.rint(lam1), 1.0e9))
-                continue
-            uu = row_uniforms(np.array([rowsd[ri]]), offset, seed, 16, draw0=SPLIT_DRAW0 + 16 * int(b))[0, :n]
-            kk, mg = poisson_icdf(np.full(n, lc, dtype=np.float32), uu)
-            Kb[ri, b] = int(kk.sum())
-            margin[ri, b] = mg.min()
+        # heavy sub-blocks (rate > 12): one independent Poisson(h r_s) per destination from the sub-block's SPLIT stream
+        # (inverse CDF up to 12, PTRS above) -- csrc/draw.hpp: subblock_draw / poisson_ptrs
+        heavy = lam_b > np.float32(POISSON_ICDF_MAX_LAMBDA)
+        heavy_move = np.zeros(nd, dtype=np.int64)
+        for ri, b in zip(*np.nonzero(heavy)):
+            uu = iter(row_uniforms(np.array([rowsd[ri]]), offset, seed, 16, draw0=SPLIT_DRAW0 + 16 * int(b))[0])
+            ktot = 0
+            for i in range(min(4, S - 4 * int(b))):
+                li = np.float32(h32 * rp[ri, b, i])
+                if not li > 0:
+                    continue
+                if li <= POISSON_ICDF_MAX_LAMBDA:
+                    kk, mg = poisson_icdf(np.array([li], dtype=np.float32), np.array([next(uu)], dtype=np.float32))
+                    k, ok = int(kk[0]), bool(mg[0] > 1e-6)
+                else:
+                    k, ok = poisson_ptrs(li, uu)
+                if not ok:
+                    dd[ri] = False
+                ktot += k
+                heavy_move[ri] += k * (4 * int(b) + i - int(bd[ri]))
+            Kb[ri, b] = min(ktot, 1 << 30)
+            margin[ri, b] = 1.0
         dd &= margin.min(-1) > 1e-6
-        # picks inside the active sub-blocks
-        for ri, b in zip(*np.nonzero(Kb > 0)):
+        # picks inside the active light sub-blocks
+        for ri, b in zip(*np.nonzero((Kb > 0) & ~heavy)):
             K = int(min(Kb[ri, b], 4096))
             nblk = (K + 3) // 4
             uu = row_uniforms(np.array([rowsd[ri]]), offset, seed, nblk, draw0=PICK_DRAW0 + 16 * int(b))[0, :K]
@@ -224,7 +264,8 @@ def tauleap_draw_replay(rates, x, h, is_ordinal, seed, offset, x_base=None):
             if (gap < 1e-5).any():
                 dd[ri] = False
             jl[ri] += int(np.sum(4 * b + i - bd[ri]))
-        cnt = Kb.sum(-1)
+        cnt = Kb.astype(np.int64).sum(-1)
+        jl = np.clip(jl + heavy_move, -S, S)                     # |jump| >= S - 1 saturates the state clamp either way
         jump[dense] = jl if is_ordinal else np.where(cnt <= 1, jl, 0)
         tmp = decided[dense]
         tmp &= dd

@@ -216,6 +216,36 @@ def test_tauleap_draw_replay(nat, S, ordinal):
     assert out.min() >= 0 and out.max() < S
 
 
+@pytest.mark.parametrize("S", [256, 16])
+def test_tauleap_draw_heavy_rates(nat, S):
+    """Rates as a random-init logistic head produces them (h r up to ~1e6 per destination): the heavy sub-block rule
+    (independent Poisson per destination, PTRS above 12) replays on the CPU, saturates the state clamp, and its
+    per-destination counts have Poisson mean and variance."""
+    N, D = 3, 200
+    g = torch.Generator().manual_seed(S)
+    rates = torch.rand(N, D, S, generator=g) ** 6 * 3e4
+    rates[1] *= 1e3                                             # up to 3e7 -> h r ~ 3e5
+    rates[2, :, : S // 2] = 0.0
+    x = torch.randint(0, S, (N, D), generator=g)
+    h = 0.01
+    out = nat.tauleap_draw(dev(rates), dev(x, torch.int32), h, True, seed=5, offset=9).cpu().long()
+    ref, decided = oph.tauleap_draw_replay(rates.numpy(), x.numpy(), h, True, 5, 9)
+    dec = T(decided)
+    assert dec.float().mean() > 0.95
+    assert torch.equal(out[dec], T(ref)[dec])
+    assert out.min() >= 0 and out.max() <= S - 1
+    below = x[2] < S // 2                                       # all rate mass above the state: saturates at S - 1
+    assert below.any() and (out[2][below] == S - 1).float().mean() > 0.95
+    # one heavy destination next to the state: x_new - x = k ~ Poisson(h r) while the clamp is inactive
+    Sb, n = 1024, 20000
+    lam = 300.0
+    r = torch.zeros(1, n, Sb)
+    r[..., 1] = lam / h                                         # (row total 300 > 64: dense regime, heavy sub-block 0)
+    x0 = torch.zeros(1, n, dtype=torch.int64)
+    k = nat.tauleap_draw(dev(r), dev(x0, torch.int32), h, True, seed=3, offset=1).cpu().double().view(-1)
+    assert abs(k.mean().item() - lam) < 6 * np.sqrt(lam / n) and abs(k.var().item() - lam) < 0.06 * lam
+
+
 def test_tauleap_draw_poisson_marginals(nat):
     """Superposition rule == independent Poisson per destination: check the jump-count marginals."""
     S, N, D = 64, 64, 4096                   # S large enough that the clamp at S-1 never binds
