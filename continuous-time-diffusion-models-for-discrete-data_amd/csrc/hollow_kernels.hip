@@ -225,6 +225,143 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
   }
 }
 
+// ------------------------------------------------------------------ bf16 matrix-core attention (throughput mode)
+// Same contract as k_hollow_attention for head dimensions 16 and 32, with the two products on
+// v_mfma_f32_32x32x16_bf16 and the softmax in fp32.  A wave owns 32 queries; per chunk of 32 keys it forms the
+// TRANSPOSED score tile S^T[key][query] = K Q^T, so that a lane's 16 accumulator registers are 16 keys of ONE query
+// (lane = query column): the online-softmax maximum and sum are 15 in-register steps plus one exchange with the lane
+// holding the other half of the keys.  The probabilities then ARE the B operand of O^T[dim][query] += V^T P^T without
+// any data movement: k-step s of that product contracts the keys held in registers 8s..8s+7 of the two lane halves
+// ({16s + 4kh + 0..3} U {16s + 8 + 4kh + 0..3} for half kh), and V^T is read from LDS in that key order.
+// 4 waves = 128 queries of one (b, head) per workgroup; K / V chunks are converted to bf16 while staged.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4h = __attribute__((ext_vector_type(4))) unsigned;
+__device__ inline unsigned hk_pack2(float a, float b) {
+  using v2f = __attribute__((ext_vector_type(2))) float;
+  using v2b = __attribute__((ext_vector_type(2))) __bf16;
+  v2f v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));
+}
+template <int HD>
+__global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnArgs a) {
+  constexpr int KS = HD / 16;                       // k-steps of the score product
+  constexpr int KLD = HD + 8, VLD = 32 + 8;         // LDS row lengths (bf16 elements): 16-byte padded
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[32 * KLD];     // [key][dim]
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[32 * VLD];     // [dim][key] (dims >= HD: zero rows)
+  const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int q0 = blockIdx.x * 128 + wave * 32;      // first query of this wave
+  const int i = q0 + col;                           // this lane's query
+  const bool qok = i < a.Tq;
+  // Q^T fragments (B operand of the score product): 8 consecutive dims of the lane's query per k-step, pre-scaled
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) {
+    unsigned w[4] = {0, 0, 0, 0};
+    if (qok) {
+      const float* qr = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * HD + 16 * s_ + 8 * kh;
+      const float4 u0 = *(const float4*)qr, u1 = *(const float4*)(qr + 4);
+      w[0] = hk_pack2(u0.x * a.scale, u0.y * a.scale); w[1] = hk_pack2(u0.z * a.scale, u0.w * a.scale);
+      w[2] = hk_pack2(u1.x * a.scale, u1.y * a.scale); w[3] = hk_pack2(u1.z * a.scale, u1.w * a.scale);
+    }
+    qf[s_] = __builtin_bit_cast(bf16x8, u32x4h{w[0], w[1], w[2], w[3]});
+  }
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
+  float m = -INFINITY, l = 0.0f;
+  if (threadIdx.x < 32 * VLD / 2) ((unsigned*)Vsm)[threadIdx.x] = 0u;          // (zero rows for HD < 32 stay zero)
+  for (int idx = threadIdx.x; idx < 32 * VLD / 2; idx += 256) ((unsigned*)Vsm)[idx] = 0u;
+  const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tq) - 1;            // query range of the workgroup
+  const int mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;                          // ... of this wave
+  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+    const int j1 = min(j0 + 32, a.Tk) - 1;
+    auto range_any = [&](int lo, int hi) {
+      if (hi < lo) return false;
+      if (a.mode == 0) return j0 <= hi;
+      if (a.mode == 1) return j1 >= lo;
+      return j0 == 0 || (j0 <= a.Tq && j0 - 1 <= hi) || (j1 > a.Tq && j1 - a.Tq - 1 >= lo);
+    };
+    if (!range_any(wlo, whi)) continue;                                        // (uniform over the workgroup)
+    __syncthreads();
+    // stage the chunk: K rows as they are, V transposed, fp32 -> bf16
+    for (int idx = threadIdx.x; idx < 32 * HD / 4; idx += 256) {
+      const int jj = idx / (HD / 4), c4 = (idx % (HD / 4)) * 4, j = j0 + jj;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (j < a.Tk) {
+        kv = *(const float4*)(a.k + (size_t)b * a.k_bs + (size_t)j * a.k_rs + h * HD + c4);
+        vv = *(const float4*)(a.v + (size_t)b * a.v_bs + (size_t)j * a.v_rs + h * HD + c4);
+      }
+      *(uint2*)(Ksm + jj * KLD + c4) = make_uint2(hk_pack2(kv.x, kv.y), hk_pack2(kv.z, kv.w));
+      Vsm[(c4 + 0) * VLD + jj] = hk_bf16(vv.x); Vsm[(c4 + 1) * VLD + jj] = hk_bf16(vv.y);
+      Vsm[(c4 + 2) * VLD + jj] = hk_bf16(vv.z); Vsm[(c4 + 3) * VLD + jj] = hk_bf16(vv.w);
+    }
+    __syncthreads();
+    if (!range_any(mylo, myhi)) continue;                                      // (wave-uniform; no barrier below)
+    // ---- S^T = K Q^T : A = K rows (lane = key col, 8 dims per half), B = Q^T fragments
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const bf16x8 kf = *(const bf16x8*)(Ksm + col * KLD + 16 * s_ + 8 * kh);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], sacc, 0, 0, 0);
+    }
+    // ---- mask + online softmax for the lane's query over its 16 keys (+ the partner lane's 16)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bool ok = qok && j < a.Tk;
+      if (a.mode == 0) ok = ok && j <= i;
+      else if (a.mode == 1) ok = ok && j >= i;
+      else ok = ok && (j == 0 || (j <= a.Tq ? j - 1 <= i : j - a.Tq - 1 >= i));
+      sacc[r] = ok ? sacc[r] : -INFINITY;
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+    const float mn = fmaxf(m, mx);
+    const float msafe = mn == -INFINITY ? 0.0f : mn;                           // a query that sees nothing in this chunk
+    const float corr = __expf(m - msafe);                                      // exp(-inf) = 0 on the first visible chunk
+    float rs = 0.0f;
+    unsigned pw[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __expf(sacc[r] - msafe), p1 = __expf(sacc[r + 1] - msafe);
+      rs += p0 + p1;
+      pw[r >> 1] = hk_pack2(p0, p1);
+    }
+    rs += __shfl_xor(rs, 32, WAVE);
+    l = l * corr + rs;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= corr;
+    // ---- O^T += V^T P^T : A = V^T rows (lane = dim col) in the key order of the probability registers
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const unsigned short* vr = Vsm + col * VLD + 16 * s_ + 4 * kh;
+      const uint2 va = *(const uint2*)vr, vb = *(const uint2*)(vr + 8);
+      const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4h{va.x, va.y, vb.x, vb.y});
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4h{pw[4 * s_], pw[4 * s_ + 1], pw[4 * s_ + 2], pw[4 * s_ + 3]});
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
+    }
+  }
+  if (qok) {
+    const float inv = 1.0f / l;
+    const size_t oo = ((size_t)b * a.Tq + i) * a.out_rs + h * HD;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int d0 = 8 * r4 + 4 * kh;                                          // dims d0..d0+3 = registers 4 r4 .. 4 r4 + 3
+      if (d0 < HD) {
+        const float4 v = make_float4(oacc[4 * r4] * inv, oacc[4 * r4 + 1] * inv, oacc[4 * r4 + 2] * inv, oacc[4 * r4 + 3] * inv);
+        if (a.out) *(float4*)(a.out + oo + d0) = v;
+        if (a.out_hi) *(uint2*)(a.out_hi + oo + d0) = make_uint2(hk_pack2(v.x, v.y), hk_pack2(v.z, v.w));
+      }
+    }
+  }
+}
+
 }  // namespace ctdd
 using namespace ctdd;
 
@@ -260,6 +397,23 @@ extern "C" int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16
   CTDD_REQUIRE(src && (dst || dst_bf16) && B > 0 && E > 0, CTDD_EINVAL, "hollow put_rows: bad arguments");
   hipLaunchKernelGGL(k_hollow_put_rows, dim3(B), dim3(256), 0, (hipStream_t)stream, src, dst, (unsigned short*)dst_bf16, dst_bs, E);
   return finish_launch("k_hollow_put_rows");
+}
+
+extern "C" int ctdd_hollow_attention_bf16(const void* args_, void* stream) {
+  const HollowAttnArgs& a = *(const HollowAttnArgs*)args_;
+  CTDD_REQUIRE(a.q && a.k && a.v && (a.out || a.out_hi), CTDD_EINVAL, "hollow attention: null buffer");
+  CTDD_REQUIRE(a.mode >= 0 && a.mode <= 2 && (a.mode != 2 || a.Tk == 2 * a.Tq + 1) && (a.mode == 2 || a.Tk == a.Tq), CTDD_EINVAL,
+               "hollow attention: mode %d with Tq=%d Tk=%d", a.mode, a.Tq, a.Tk);
+  CTDD_REQUIRE(a.q_rs % 4 == 0 && a.k_rs % 4 == 0 && a.v_rs % 4 == 0 && a.out_rs % 4 == 0 && a.q_bs % 4 == 0 && a.k_bs % 4 == 0 && a.v_bs % 4 == 0,
+               CTDD_EINVAL, "hollow attention: strides must be multiples of 4 floats");
+  const dim3 g((a.Tq + 127) / 128, a.H, a.B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.hd) {
+    case 16: hipLaunchKernelGGL(k_hollow_attention_mfma<16>, g, dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL(k_hollow_attention_mfma<32>, g, dim3(256), 0, st, a); break;
+    default: CTDD_REQUIRE(false, CTDD_ERANGE, "bf16 hollow attention: head dim %d (16 or 32)", a.hd);
+  }
+  return finish_launch("k_hollow_attention_mfma");
 }
 
 extern "C" int ctdd_hollow_attention(const void* args_, void* stream) {

@@ -52,7 +52,8 @@ def _lib():
     if not _sigs_done:
         for name, argt in (("ctdd_hollow_embed", [_P, _P]), ("ctdd_hollow_layernorm", [_P, _P]),
                            ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _P, _I64, _I, _I64, _P]),
-                           ("ctdd_hollow_put_rows", [_P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P])):
+                           ("ctdd_hollow_put_rows", [_P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P]),
+                           ("ctdd_hollow_attention_bf16", [_P, _P])):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -163,7 +164,8 @@ class HollowEngine:
             a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale, a.out, a.out_rs = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd), P(out), E
             a.out_hi = P(out_hi)
             keep.append(a)
-            launch(lib.ctdd_hollow_attention, C.byref(a), label=f"attention mode {mode} {Tq}x{Tk}")
+            fn = lib.ctdd_hollow_attention_bf16 if (fast and hd in (16, 32) and getattr(m, "engine_attention", "mfma") == "mfma") else lib.ctdd_hollow_attention
+            launch(fn, C.byref(a), label=f"attention mode {mode} {Tq}x{Tk}")
 
         R = B * D
         # ---- embedding

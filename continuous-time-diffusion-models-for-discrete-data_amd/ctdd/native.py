@@ -56,7 +56,7 @@ _SIGS = {
 }
 UNET_EXPORTS = ("ctdd_unet_conv", "ctdd_unet_conv_patch", "ctdd_unet_conv_res", "ctdd_unet_conv_ring", "ctdd_unet_upsample2x", "ctdd_unet_first_conv", "ctdd_unet_gn_apply", "ctdd_unet_channel_stats",
                 "ctdd_unet_time", "ctdd_unet_attention", "ctdd_unet_logistic_head")    # bound in ctdd/unet_engine.py
-HOLLOW_EXPORTS = ("ctdd_hollow_embed", "ctdd_hollow_layernorm", "ctdd_hollow_add", "ctdd_hollow_put_rows", "ctdd_hollow_attention")
+HOLLOW_EXPORTS = ("ctdd_hollow_embed", "ctdd_hollow_layernorm", "ctdd_hollow_add", "ctdd_hollow_put_rows", "ctdd_hollow_attention", "ctdd_hollow_attention_bf16")
 EXPORTS = tuple(_SIGS) + UNET_EXPORTS + HOLLOW_EXPORTS
 
 

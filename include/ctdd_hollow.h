@@ -42,6 +42,8 @@ typedef struct {
   void* out_bf16;                                 /* optional bf16 copy of the output */
 } ctdd_hollow_attn_args;
 int ctdd_hollow_attention(const void* attn_args, void* stream);
+/* same contract with both products on the bf16 matrix cores (fp32 softmax); head dimension 16 or 32 */
+int ctdd_hollow_attention_bf16(const void* attn_args, void* stream);
 
 #ifdef __cplusplus
 }

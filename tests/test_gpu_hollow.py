@@ -69,3 +69,45 @@ def test_hollow_engine_matches_module_maze():
     # bf16 GEMM operands (throughput mode): reported separately, looser bar
     assert (fast - ref).abs().max().item() < 5e-2 * max(ref.abs().max().item(), 1.0)
     model.train()
+
+
+@pytest.mark.parametrize("hd", [16, 32])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_attention_kernels_against_masked_softmax(hd, mode):
+    """Both attention kernels (fp32 FMA; bf16 matrix cores) against a torch masked softmax, through the C ABI.
+    Ragged length (T = 197: 128 + 69, chunks of 32 with a 5-key tail).  fp32: 2e-5; bf16 operands: 2e-2."""
+    import ctypes as C
+    from ctdd.hollow_engine import _AttnArgs, _lib
+    lib = _lib()
+    B, H, Tq = 3, 4, 197
+    Tk = 2 * Tq + 1 if mode == 2 else Tq
+    E = H * hd
+    g = torch.Generator(device="cuda").manual_seed(5 + hd + mode)
+    q = torch.randn(B, Tq, E, device="cuda", generator=g)
+    k = torch.randn(B, Tk, E, device="cuda", generator=g)
+    v = torch.randn(B, Tk, E, device="cuda", generator=g)
+    i = torch.arange(Tq, device="cuda")[:, None]
+    j = torch.arange(Tk, device="cuda")[None, :]
+    if mode == 0:
+        ok = j <= i
+    elif mode == 1:
+        ok = j >= i
+    else:
+        ok = (j == 0) | ((j >= 1) & (j <= Tq) & (j - 1 <= i)) | ((j > Tq) & (j - Tq - 1 >= i))
+    qh, kh, vh = (z.view(B, -1, H, hd).transpose(1, 2).double() for z in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) / hd ** 0.5
+    s = s.masked_fill(~ok, float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, E).float()
+    st = torch.cuda.current_stream().cuda_stream
+    for fn, tol in ((lib.ctdd_hollow_attention, 2e-5), (lib.ctdd_hollow_attention_bf16, 2e-2)):
+        out = torch.full((B, Tq, E), float("nan"), device="cuda")
+        out_hi = torch.zeros(B, Tq, E, device="cuda", dtype=torch.bfloat16)
+        a = _AttnArgs()
+        a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+        a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
+        a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / hd ** 0.5
+        a.out, a.out_rs, a.out_hi = out.data_ptr(), E, out_hi.data_ptr()
+        assert fn(C.byref(a), st) == 0
+        torch.cuda.synchronize()
+        assert (out - ref).abs().max().item() < tol, fn
+        assert (out_hi.float() - ref).abs().max().item() < max(tol, 2e-2), fn
