@@ -185,6 +185,7 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
   // (260 scalar loads, each followed by a wait, in this unrolled epilogue).  Pin the integer fields in scalar registers.
   auto pin32 = [](int v) { asm volatile("" : "+s"(v)); return v; };
   const int aN = pin32(a.N), aB = pin32(a.B), a_tbs = pin32(a.tb_stride), a_lc = pin32(a.logits_C);
+  const int a_act = pin32(a.act);
   // (pointers stay as they are: laundering them through an integer loses the global address space -> flat_load/flat_store)
   float* const p_out_f32 = a.out_f32;
   unsigned short* const p_out_hi = a.out_hi;
@@ -252,6 +253,13 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bv[j] + (second ? tb1[j] : tb0[j]);
+        if (a_act == 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.0f);
+        } else if (a_act == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+        }
         const size_t o = (size_t)p * aN + nc;
         if (p_res_bf16) {
           const uint4 rr = rres[step];

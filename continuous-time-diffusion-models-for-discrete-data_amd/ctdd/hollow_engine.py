@@ -146,6 +146,22 @@ class HollowEngine:
             else:
                 bk = 32 if K % 32 == 0 else 16
                 bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
+            if use_bf16 and N % 8 == 0 and K % 16 == 0 and getattr(m, "engine_linear", "patch") == "patch":
+                # the U-Net's slab kernel run as a plain GEMM (one 1x1 segment over a rows x 1 "image"): 16-byte row-major
+                # epilogue, weights and activations staged per 128/256-row tile
+                pbk = 64 if K % 64 == 0 else 48 if K % 48 == 0 else 32 if K % 32 == 0 else 16
+                if pbk == 64:
+                    pbnt = 4 if N > 64 else 2 if N > 32 else 1
+                elif pbk == 48:
+                    pbnt = 4 if N % 128 == 0 else 3 if N > 64 else 2 if N > 32 else 1
+                elif pbk == 32:
+                    pbnt = 4 if N % 128 == 0 else 3 if N > 32 else 1
+                else:
+                    pbnt = 1
+                wm = 64 if (rows >= 256 * 256 and (pbk, pbnt) in ((48, 3), (48, 4), (64, 4), (64, 2), (48, 2))) else 32
+                launch(lib.ctdd_unet_conv_patch, C.byref(a), pbk, pbnt, wm, label=f"linear {label} {rows}x{K}->{N} patch",
+                       flops=2 * rows * K * N)
+                return
             launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, 0 if use_bf16 else 1, label=f"linear {label} {rows}x{K}->{N}",
                    flops=2 * rows * K * N)
 

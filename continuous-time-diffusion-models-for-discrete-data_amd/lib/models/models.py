@@ -121,7 +121,9 @@ class HollowTransformer(nn.Module):
         if self._use_engine(x):
             from ctdd import hollow_engine
             if self._engine is None:
-                self._engine = hollow_engine.HollowEngine(self)
+                # cfg.model.engine_precision = "bf16": bf16 matrix-core GEMMs and attention (fp32 accumulation / softmax /
+                # LayerNorm), ~3.4x the fp32 forward rate at ~1e-3 absolute logit error; default "fp32" holds the 1e-4 bar
+                self._engine = hollow_engine.HollowEngine(self, precision=getattr(self.cfg.model, "engine_precision", "fp32"))
             return self._engine(x, times)
         return self.net(x, times)
 
