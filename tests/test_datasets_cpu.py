@@ -88,3 +88,56 @@ def test_exp_hamming_mmd_matches_dense_formula():
     got = binary_exp_hamming_mmd(x, y)
     np.testing.assert_allclose(got.item(), want.item(), rtol=1e-5)
     assert binary_exp_hamming_mmd(x, x.clone()).abs().item() < 0.05 and got.item() > 0.01
+
+
+def test_maze_generation_and_accuracy():
+    """Maze3S data (reference lib/datasets/maze.py:758-966): perfect 7x7-cell mazes on a 15x15 grid, solved by BFS;
+    maze_acc accepts exactly the samples that equal the solved form of their own walls."""
+    import random
+    import lib.datasets.maze as mz
+    rng = random.Random(3)
+    for random_entry in (False, True):
+        g = mz.grow_tree_maze(rng, random_entry=random_entry)
+        assert g.shape == (15, 15)
+        # a spanning tree over 49 cells: 49 cells + 48 passages + 2 openings are floor, the rest wall
+        assert (g == mz.FLOOR).sum() == 49 + 48 + 2 and (g == mz.WALL).sum() == 225 - 99
+        assert (g[1::2, 1::2] == mz.FLOOR).all() and (g[0::2, 0::2] == mz.WALL).all()
+        assert len(mz.find_entries(g)) == 2
+        if not random_entry:
+            assert g[0, 1] == mz.FLOOR and g[14, 13] == mz.FLOOR
+        s = mz.find_path(g.copy(), random_entry)
+        assert s is not None and (s == mz.PATH).sum() >= 15 and s[(s != mz.PATH)].tolist() == g[(s != mz.PATH)].tolist()
+    data = mz.maze_gen(16, device="cpu", seed=11)
+    again = mz.maze_gen(16, device="cpu", seed=11)
+    assert data.shape == (16, 1, 15, 15) and data.dtype == torch.int64 and torch.equal(data, again)
+    assert set(np.unique(data.numpy()).tolist()) == {0, 1, 2}
+    valid = mz.maze_acc(data.numpy().reshape(16, -1), verbose=False)
+    assert valid.shape == (16, 15, 15) and mz.maze_acc.last["accuracy"] == 1.0
+    # corrupt half of them: a path cell turned into free floor is no longer the solved form
+    bad = data.numpy().reshape(16, 15, 15).copy()
+    for i in range(8):
+        ys, xs = np.nonzero(bad[i] == mz.PATH)
+        bad[i, ys[3], xs[3]] = mz.FLOOR
+    valid = mz.maze_acc(bad, verbose=False)
+    assert valid.shape[0] == 8 and abs(mz.maze_acc.last["accuracy"] - 0.5) < 1e-12
+    assert mz.maze_acc(np.zeros((2, 225), dtype=np.int64), verbose=False).shape == (0, 15, 15)
+    # BFS tie-break: a 2-wide room has two shortest paths; the first direction of the reference's order wins
+    room = np.zeros((15, 15), dtype=np.int64)
+    room[0, 1] = room[14, 13] = 2
+    room[1:14, 1:14] = 2
+    s = mz.find_path(room.copy(), True)
+    assert (s == 1).sum() == 27 and s[1, 13] == 1 and s[13, 1] == 2       # goes right along the top first, then down
+
+
+def test_maze_dataset_registry():
+    import lib.datasets.maze  # noqa: F401
+    import lib.datasets.dataset_utils as du
+    from config.maze_config.config_hollow_maze import get_config
+    cfg = get_config()
+    ds = du.get_dataset(cfg, "cpu")
+    assert len(ds) == cfg.data.batch_size
+    item = ds[0]
+    assert item.shape == (1, 15, 15) and int(item.max()) <= 2
+    cfg.data.name, cfg.data.limit = "Maze3SComplete", 5
+    full = du.get_dataset(cfg, "cpu")
+    assert len(full) == 5 and full[4].shape == (1, 15, 15)
