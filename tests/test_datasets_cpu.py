@@ -141,3 +141,37 @@ def test_maze_dataset_registry():
     cfg.data.name, cfg.data.limit = "Maze3SComplete", 5
     full = du.get_dataset(cfg, "cpu")
     assert len(full) == 5 and full[4].shape == (1, 15, 15)
+
+
+def test_frechet_distance_plumbing():
+    """FID plumbing (reference lib/datasets/mnist_fid.py:74-192) with a stand-in feature network: closed forms of the
+    Frechet distance, and the image path (scaling by S-1, grey -> 3 channels, statistics in fp64)."""
+    import pytest
+    import lib.datasets.mnist_fid as fid
+    rng = np.random.default_rng(0)
+    d = 6
+    a, b = rng.uniform(0.5, 2.0, d), rng.uniform(0.5, 2.0, d)
+    m1, m2 = rng.normal(size=d), rng.normal(size=d)
+    # commuting (diagonal) covariances: |dm|^2 + sum (sqrt a - sqrt b)^2
+    want = ((m1 - m2) ** 2).sum() + ((np.sqrt(a) - np.sqrt(b)) ** 2).sum()
+    assert abs(fid.calculate_frechet_distance(m1, np.diag(a), m2, np.diag(b)) - want) < 1e-9
+    q = np.linalg.qr(rng.normal(size=(d, d)))[0]
+    s1 = q @ np.diag(a) @ q.T
+    assert abs(fid.calculate_frechet_distance(m1, s1, m1, s1)) < 1e-8
+    with pytest.raises(ValueError):
+        fid.calculate_frechet_distance(m1, s1, m2[:3], s1[:3, :3])
+
+    class Feat(torch.nn.Module):                       # (B, 3, H, W) -> (B, 4, 2, 2) maps, returned in a list as InceptionV3 does
+        def forward(self, x):
+            return [torch.nn.functional.adaptive_avg_pool2d(x[:, :1] * torch.tensor([1.0, 2.0, -1.0, 0.5]).view(1, 4, 1, 1), 2)]
+
+    x1 = rng.integers(0, 256, (40, 1, 8, 8))
+    x2 = rng.integers(0, 128, (33, 1, 8, 8))
+    got = fid.evaluate_fid_score(x1, x2, batch_size=16, model=Feat(), dims=4, device="cpu")
+    f1 = (x1 / 255.0).mean(axis=(1, 2, 3))[:, None] * np.array([1.0, 2.0, -1.0, 0.5])
+    f2 = (x2 / 255.0).mean(axis=(1, 2, 3))[:, None] * np.array([1.0, 2.0, -1.0, 0.5])
+    want = fid.calculate_frechet_distance(f1.mean(0), np.cov(f1, rowvar=False), f2.mean(0), np.cov(f2, rowvar=False))
+    assert abs(got - want) < 1e-5 * max(1.0, abs(want))     # (features pass through fp32 in the network)
+    assert abs(fid.evaluate_fid_score(x1, x1, model=Feat(), dims=4, device="cpu")) < 1e-5
+    with pytest.raises(RuntimeError):
+        fid.evaluate_fid_score(x1, x2)
