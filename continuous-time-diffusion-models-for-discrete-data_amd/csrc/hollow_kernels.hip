@@ -20,6 +20,9 @@ __device__ inline unsigned short hk_bf16(float a) {            // round-to-neare
   return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b)) & 0xFFFFu);
 }
 
+// second bf16 term of a value: v ~ hi + lo to ~2^-17 relative (the "split" GEMM operands)
+__device__ inline unsigned short hk_lo(float v, unsigned short hi) { return hk_bf16(v - __uint_as_float((unsigned)hi << 16)); }
+
 // ------------------------------------------------------------------ embedding (hollow_networks.py:729-753, 534-563)
 struct HollowEmbedArgs {
   const int64_t* x64; const int32_t* x32;       // (B, D) states
@@ -61,6 +64,7 @@ struct HollowLnArgs {
   int B, T, E;
   float* out;
   unsigned short* out_hi; int64_t out_hi_bs;      // optional bf16 copy (GEMM operand in the bf16 mode)
+  unsigned short* out_lo;                         // optional second bf16 term, bf16(v - out_hi) (split mode), stride out_hi_bs
 };
 __global__ __launch_bounds__(256) void k_hollow_layernorm(const HollowLnArgs a) {
   const int lane = threadIdx.x & 63;
@@ -81,29 +85,42 @@ __global__ __launch_bounds__(256) void k_hollow_layernorm(const HollowLnArgs a) 
     float v = (x[e] + (y ? y[e] : 0.0f) - mean) * rstd * a.gamma[e] + a.beta[e];
     if (a.film) v = a.film[(size_t)b * a.film_stride + e] * v + a.film[(size_t)b * a.film_stride + E + e];
     if (o) o[e] = v;
-    if (oh) oh[e] = hk_bf16(v);
+    if (oh) {
+      const unsigned short hv = hk_bf16(v);
+      oh[e] = hv;
+      if (a.out_lo) a.out_lo[(size_t)b * a.out_hi_bs + (size_t)j * E + e] = hk_lo(v, hv);
+    }
   }
 }
 
 // out[b][j][:] = p[b][j][:] + q[b][j][:], strided batches
 __global__ __launch_bounds__(256) void k_hollow_add(const float* __restrict__ p, int64_t p_bs, const float* __restrict__ q, int64_t q_bs,
-                                                   float* __restrict__ out, unsigned short* __restrict__ out_hi, int64_t out_bs,
-                                                   int64_t per_batch) {
+                                                   float* __restrict__ out, unsigned short* __restrict__ out_hi,
+                                                   unsigned short* __restrict__ out_lo, int64_t out_bs, int64_t per_batch) {
   const int b = blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_batch; i += (int64_t)gridDim.x * 256) {
     const float v = p[(size_t)b * p_bs + i] + q[(size_t)b * q_bs + i];
     if (out) out[(size_t)b * out_bs + i] = v;
-    if (out_hi) out_hi[(size_t)b * out_bs + i] = hk_bf16(v);
+    if (out_hi) {
+      const unsigned short hv = hk_bf16(v);
+      out_hi[(size_t)b * out_bs + i] = hv;
+      if (out_lo) out_lo[(size_t)b * out_bs + i] = hk_lo(v, hv);
+    }
   }
 }
 // rows of a (B, E) matrix into slot 0 of a (B, T, E) buffer
 __global__ __launch_bounds__(256) void k_hollow_put_rows(const float* __restrict__ src, float* __restrict__ dst,
-                                                        unsigned short* __restrict__ dst_hi, int64_t dst_bs, int E) {
+                                                        unsigned short* __restrict__ dst_hi, unsigned short* __restrict__ dst_lo,
+                                                        int64_t dst_bs, int E) {
   const int b = blockIdx.x;
   for (int e = threadIdx.x; e < E; e += 256) {
     const float v = src[(size_t)b * E + e];
     if (dst) dst[(size_t)b * dst_bs + e] = v;
-    if (dst_hi) dst_hi[(size_t)b * dst_bs + e] = hk_bf16(v);
+    if (dst_hi) {
+      const unsigned short hv = hk_bf16(v);
+      dst_hi[(size_t)b * dst_bs + e] = hv;
+      if (dst_lo) dst_lo[(size_t)b * dst_bs + e] = hk_lo(v, hv);
+    }
   }
 }
 
@@ -116,6 +133,8 @@ struct HollowAttnArgs {
   int B, Tq, Tk, H, hd, mode; float scale;
   float* out; int out_rs;
   unsigned short* out_hi;                        // optional bf16 copy, same row stride
+  unsigned short* out_lo;                        // optional second bf16 term of the output (split mode)
+  int split;                                     // matrix-core kernel: 1 = three bf16 products per contraction (hi hi + lo hi + hi lo)
 };
 // One thread = one query with the whole head dimension in registers (q[HD], acc[HD]); a workgroup = 128
 // consecutive queries of one (b, head); keys / values come through LDS in chunks of 32 and are read as
@@ -220,6 +239,10 @@ __global__ __launch_bounds__(AQ) void k_hollow_attention(const HollowAttnArgs a)
       if (a.out_hi) {
         unsigned short* oh = a.out_hi + oo + c;
         oh[0] = hk_bf16(v.x); oh[1] = hk_bf16(v.y); oh[2] = hk_bf16(v.z); oh[3] = hk_bf16(v.w);
+        if (a.out_lo) {
+          unsigned short* ol = a.out_lo + oo + c;
+          ol[0] = hk_lo(v.x, oh[0]); ol[1] = hk_lo(v.y, oh[1]); ol[2] = hk_lo(v.z, oh[2]); ol[3] = hk_lo(v.w, oh[3]);
+        }
       }
     }
   }
@@ -243,36 +266,43 @@ __device__ inline unsigned hk_pack2(float a, float b) {
   v2f v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));
 }
-template <int HD>
+template <int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnArgs a) {
   constexpr int KS = HD / 16;                       // k-steps of the score product
   constexpr int KLD = HD + 8, VLD = 32 + 8;         // LDS row lengths (bf16 elements): 16-byte padded
-  __shared__ __attribute__((aligned(16))) unsigned short Ksm[32 * KLD];     // [key][dim]
-  __shared__ __attribute__((aligned(16))) unsigned short Vsm[32 * VLD];     // [dim][key] (dims >= HD: zero rows)
+  constexpr int NT = SPLIT ? 2 : 1;                 // terms per operand: hi (+ lo)
+  __shared__ __attribute__((aligned(16))) unsigned short Ksm[NT][32 * KLD];     // [key][dim]
+  __shared__ __attribute__((aligned(16))) unsigned short Vsm[NT][32 * VLD];     // [dim][key] (dims >= HD: zero rows)
   const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, kh = lane >> 5;
   const int q0 = blockIdx.x * 128 + wave * 32;      // first query of this wave
   const int i = q0 + col;                           // this lane's query
   const bool qok = i < a.Tq;
   // Q^T fragments (B operand of the score product): 8 consecutive dims of the lane's query per k-step, pre-scaled
-  bf16x8 qf[KS];
+  bf16x8 qf[NT][KS];
 #pragma unroll
   for (int s_ = 0; s_ < KS; ++s_) {
-    unsigned w[4] = {0, 0, 0, 0};
+    float qv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qok) {
       const float* qr = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * HD + 16 * s_ + 8 * kh;
       const float4 u0 = *(const float4*)qr, u1 = *(const float4*)(qr + 4);
-      w[0] = hk_pack2(u0.x * a.scale, u0.y * a.scale); w[1] = hk_pack2(u0.z * a.scale, u0.w * a.scale);
-      w[2] = hk_pack2(u1.x * a.scale, u1.y * a.scale); w[3] = hk_pack2(u1.z * a.scale, u1.w * a.scale);
+      qv[0] = u0.x * a.scale; qv[1] = u0.y * a.scale; qv[2] = u0.z * a.scale; qv[3] = u0.w * a.scale;
+      qv[4] = u1.x * a.scale; qv[5] = u1.y * a.scale; qv[6] = u1.z * a.scale; qv[7] = u1.w * a.scale;
     }
-    qf[s_] = __builtin_bit_cast(bf16x8, u32x4h{w[0], w[1], w[2], w[3]});
+    unsigned w[4], wl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[j] = hk_pack2(qv[2 * j], qv[2 * j + 1]);
+      wl[j] = hk_pack2(qv[2 * j] - __uint_as_float(w[j] << 16), qv[2 * j + 1] - __uint_as_float(w[j] & 0xFFFF0000u));
+    }
+    qf[0][s_] = __builtin_bit_cast(bf16x8, u32x4h{w[0], w[1], w[2], w[3]});
+    if (SPLIT) qf[NT - 1][s_] = __builtin_bit_cast(bf16x8, u32x4h{wl[0], wl[1], wl[2], wl[3]});
   }
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
   float m = -INFINITY, l = 0.0f;
-  if (threadIdx.x < 32 * VLD / 2) ((unsigned*)Vsm)[threadIdx.x] = 0u;          // (zero rows for HD < 32 stay zero)
-  for (int idx = threadIdx.x; idx < 32 * VLD / 2; idx += 256) ((unsigned*)Vsm)[idx] = 0u;
+  for (int idx = threadIdx.x; idx < NT * 32 * VLD / 2; idx += 256) ((unsigned*)&Vsm[0][0])[idx] = 0u;   // (rows >= HD stay zero)
   const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tq) - 1;            // query range of the workgroup
   const int mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;                          // ... of this wave
   for (int j0 = 0; j0 < a.Tk; j0 += 32) {
@@ -285,7 +315,7 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
     };
     if (!range_any(wlo, whi)) continue;                                        // (uniform over the workgroup)
     __syncthreads();
-    // stage the chunk: K rows as they are, V transposed, fp32 -> bf16
+    // stage the chunk: K rows as they are, V transposed, fp32 -> bf16 (hi, and the remainder lo in the split mode)
     for (int idx = threadIdx.x; idx < 32 * HD / 4; idx += 256) {
       const int jj = idx / (HD / 4), c4 = (idx % (HD / 4)) * 4, j = j0 + jj;
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -293,9 +323,19 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
         kv = *(const float4*)(a.k + (size_t)b * a.k_bs + (size_t)j * a.k_rs + h * HD + c4);
         vv = *(const float4*)(a.v + (size_t)b * a.v_bs + (size_t)j * a.v_rs + h * HD + c4);
       }
-      *(uint2*)(Ksm + jj * KLD + c4) = make_uint2(hk_pack2(kv.x, kv.y), hk_pack2(kv.z, kv.w));
-      Vsm[(c4 + 0) * VLD + jj] = hk_bf16(vv.x); Vsm[(c4 + 1) * VLD + jj] = hk_bf16(vv.y);
-      Vsm[(c4 + 2) * VLD + jj] = hk_bf16(vv.z); Vsm[(c4 + 3) * VLD + jj] = hk_bf16(vv.w);
+      const unsigned k01 = hk_pack2(kv.x, kv.y), k23 = hk_pack2(kv.z, kv.w);
+      *(uint2*)(&Ksm[0][jj * KLD + c4]) = make_uint2(k01, k23);
+      const float ve[4] = {vv.x, vv.y, vv.z, vv.w};
+      unsigned short vh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { vh[e] = hk_bf16(ve[e]); Vsm[0][(c4 + e) * VLD + jj] = vh[e]; }
+      if (SPLIT) {
+        *(uint2*)(&Ksm[NT - 1][jj * KLD + c4]) =
+            make_uint2(hk_pack2(kv.x - __uint_as_float(k01 << 16), kv.y - __uint_as_float(k01 & 0xFFFF0000u)),
+                       hk_pack2(kv.z - __uint_as_float(k23 << 16), kv.w - __uint_as_float(k23 & 0xFFFF0000u)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Vsm[NT - 1][(c4 + e) * VLD + jj] = hk_lo(ve[e], vh[e]);
+      }
     }
     __syncthreads();
     if (!range_any(mylo, myhi)) continue;                                      // (wave-uniform; no barrier below)
@@ -305,8 +345,13 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
     for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
 #pragma unroll
     for (int s_ = 0; s_ < KS; ++s_) {
-      const bf16x8 kf = *(const bf16x8*)(Ksm + col * KLD + 16 * s_ + 8 * kh);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], sacc, 0, 0, 0);
+      const bf16x8 kf = *(const bf16x8*)(&Ksm[0][col * KLD + 16 * s_ + 8 * kh]);
+      if (SPLIT) {                                                              // small terms first
+        const bf16x8 kl = *(const bf16x8*)(&Ksm[NT - 1][col * KLD + 16 * s_ + 8 * kh]);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qf[0][s_], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[NT - 1][s_], sacc, 0, 0, 0);
+      }
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][s_], sacc, 0, 0, 0);
     }
     // ---- mask + online softmax for the lane's query over its 16 keys (+ the partner lane's 16)
     float mx = -INFINITY;
@@ -325,12 +370,13 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
     const float msafe = mn == -INFINITY ? 0.0f : mn;                           // a query that sees nothing in this chunk
     const float corr = __expf(m - msafe);                                      // exp(-inf) = 0 on the first visible chunk
     float rs = 0.0f;
-    unsigned pw[8];
+    unsigned pw[8], pl[8];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const float p0 = __expf(sacc[r] - msafe), p1 = __expf(sacc[r + 1] - msafe);
       rs += p0 + p1;
       pw[r >> 1] = hk_pack2(p0, p1);
+      if (SPLIT) pl[r >> 1] = hk_pack2(p0 - __uint_as_float(pw[r >> 1] << 16), p1 - __uint_as_float(pw[r >> 1] & 0xFFFF0000u));
     }
     rs += __shfl_xor(rs, 32, WAVE);
     l = l * corr + rs;
@@ -340,10 +386,18 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
     // ---- O^T += V^T P^T : A = V^T rows (lane = dim col) in the key order of the probability registers
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
-      const unsigned short* vr = Vsm + col * VLD + 16 * s_ + 4 * kh;
+      const unsigned short* vr = &Vsm[0][col * VLD + 16 * s_ + 4 * kh];
       const uint2 va = *(const uint2*)vr, vb = *(const uint2*)(vr + 8);
       const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4h{va.x, va.y, vb.x, vb.y});
       const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4h{pw[4 * s_], pw[4 * s_ + 1], pw[4 * s_ + 2], pw[4 * s_ + 3]});
+      if (SPLIT) {
+        const unsigned short* vq = &Vsm[NT - 1][col * VLD + 16 * s_ + 4 * kh];
+        const uint2 vc = *(const uint2*)vq, vd = *(const uint2*)(vq + 8);
+        const bf16x8 vl = __builtin_bit_cast(bf16x8, u32x4h{vc.x, vc.y, vd.x, vd.y});
+        const bf16x8 pq = __builtin_bit_cast(bf16x8, u32x4h{pl[4 * s_], pl[4 * s_ + 1], pl[4 * s_ + 2], pl[4 * s_ + 3]});
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, pf, oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pq, oacc, 0, 0, 0);
+      }
       oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc, 0, 0, 0);
     }
   }
@@ -356,7 +410,14 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
       if (d0 < HD) {
         const float4 v = make_float4(oacc[4 * r4] * inv, oacc[4 * r4 + 1] * inv, oacc[4 * r4 + 2] * inv, oacc[4 * r4 + 3] * inv);
         if (a.out) *(float4*)(a.out + oo + d0) = v;
-        if (a.out_hi) *(uint2*)(a.out_hi + oo + d0) = make_uint2(hk_pack2(v.x, v.y), hk_pack2(v.z, v.w));
+        if (a.out_hi) {
+          const unsigned h01 = hk_pack2(v.x, v.y), h23 = hk_pack2(v.z, v.w);
+          *(uint2*)(a.out_hi + oo + d0) = make_uint2(h01, h23);
+          if (a.out_lo)
+            *(uint2*)(a.out_lo + oo + d0) =
+                make_uint2(hk_pack2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xFFFF0000u)),
+                           hk_pack2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xFFFF0000u)));
+        }
       }
     }
   }
@@ -383,19 +444,20 @@ extern "C" int ctdd_hollow_layernorm(const void* args_, void* stream) {
   return finish_launch("k_hollow_layernorm");
 }
 
-extern "C" int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, int64_t out_bs,
-                               int B, int64_t per_batch, void* stream) {
+extern "C" int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, void* out_lo,
+                               int64_t out_bs, int B, int64_t per_batch, void* stream) {
   CTDD_REQUIRE(p && q && (out || out_bf16) && B > 0 && per_batch > 0, CTDD_EINVAL, "hollow add: bad arguments");
   int gx = (int)((per_batch + 2047) / 2048);
   gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-  hipLaunchKernelGGL(k_hollow_add, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, p, p_bs, q, q_bs, out, (unsigned short*)out_bf16, out_bs,
-                     per_batch);
+  hipLaunchKernelGGL(k_hollow_add, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, p, p_bs, q, q_bs, out, (unsigned short*)out_bf16,
+                     (unsigned short*)out_lo, out_bs, per_batch);
   return finish_launch("k_hollow_add");
 }
 
-extern "C" int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, int64_t dst_bs, int B, int E, void* stream) {
+extern "C" int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, void* dst_lo, int64_t dst_bs, int B, int E, void* stream) {
   CTDD_REQUIRE(src && (dst || dst_bf16) && B > 0 && E > 0, CTDD_EINVAL, "hollow put_rows: bad arguments");
-  hipLaunchKernelGGL(k_hollow_put_rows, dim3(B), dim3(256), 0, (hipStream_t)stream, src, dst, (unsigned short*)dst_bf16, dst_bs, E);
+  hipLaunchKernelGGL(k_hollow_put_rows, dim3(B), dim3(256), 0, (hipStream_t)stream, src, dst, (unsigned short*)dst_bf16,
+                     (unsigned short*)dst_lo, dst_bs, E);
   return finish_launch("k_hollow_put_rows");
 }
 
@@ -409,8 +471,14 @@ extern "C" int ctdd_hollow_attention_bf16(const void* args_, void* stream) {
   const dim3 g((a.Tq + 127) / 128, a.H, a.B);
   hipStream_t st = (hipStream_t)stream;
   switch (a.hd) {
-    case 16: hipLaunchKernelGGL(k_hollow_attention_mfma<16>, g, dim3(256), 0, st, a); break;
-    case 32: hipLaunchKernelGGL(k_hollow_attention_mfma<32>, g, dim3(256), 0, st, a); break;
+    case 16:
+      if (a.split) hipLaunchKernelGGL((k_hollow_attention_mfma<16, true>), g, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_hollow_attention_mfma<16, false>), g, dim3(256), 0, st, a);
+      break;
+    case 32:
+      if (a.split) hipLaunchKernelGGL((k_hollow_attention_mfma<32, true>), g, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_hollow_attention_mfma<32, false>), g, dim3(256), 0, st, a);
+      break;
     default: CTDD_REQUIRE(false, CTDD_ERANGE, "bf16 hollow attention: head dim %d (16 or 32)", a.hd);
   }
   return finish_launch("k_hollow_attention_mfma");

@@ -62,7 +62,8 @@ struct ConvArgs {
   int logits_C;               // > 0: out_f32 is (B, logits_C*H*W, N/logits_C): row = c*HW + p
   int ksplit;                 // > 1: grid.z workgroups each take a share of K and add into acc_buf
   float* acc_buf;             // [M][N] fp32, zeroed by the caller; finished by k_conv_finish
-  int act;                    // generic kernel only: 0 none, 1 ReLU, 2 GELU (erf), applied to acc + bias before the residual
+  int act;                    // 0 none, 1 ReLU, 2 GELU (erf), applied to acc + bias before the residual
+  unsigned short* out_lo;     // row-major epilogue only: bf16(v - out_hi), the second term of a split operand, or null
 };
 
 constexpr int BM = 128;
@@ -170,8 +171,8 @@ __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, 
 // Each lane keeps its piece's column sums / sums of squares in fp32 over the <= 8 rows it visits per
 // sample and adds them to the workgroup's fp64 LDS statistics.
 // xt = this wave's [32][32*BNT + 4] fp32 region; rows wrow0 .. wrow0 + 32*MT of the output.
-template <int BNT, int MT>
-__device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)[MT][BNT], float* xt, int64_t wrow0, int n0,
+template <int BNT, int MT, bool LO = false>
+__device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)[MT][BNT], float* xt, int64_t wrow0, int n0,
                                           int64_t M, int HW, const TileStats& ts, unsigned long long* epi_t = nullptr) {
 #ifdef CTDD_RES_STAMPS
   unsigned long long e0, e1, e2, e3;
@@ -189,6 +190,7 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
   // (pointers stay as they are: laundering them through an integer loses the global address space -> flat_load/flat_store)
   float* const p_out_f32 = a.out_f32;
   unsigned short* const p_out_hi = a.out_hi;
+  unsigned short* const p_out_lo = LO ? a.out_lo : nullptr;   // (second bf16 term: the patch kernel only)
   const unsigned short* const p_res_bf16 = a.res_bf16;
   const float* const p_res_f32 = a.res_f32;
   const float* const p_tbias = a.tbias;
@@ -282,8 +284,18 @@ __device__ inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)
           *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
-        if (p_out_hi)
-          *(uint4*)(p_out_hi + o) = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+        if (p_out_hi) {
+          const uint4 hv = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
+          *(uint4*)(p_out_hi + o) = hv;
+          if (p_out_lo) {
+            const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w};
+            unsigned lw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              lw[j] = pack2_bf16(v[2 * j] - __uint_as_float(hw[j] << 16), v[2 * j + 1] - __uint_as_float(hw[j] & 0xFFFF0000u));
+            *(uint4*)(p_out_lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+          }
+        }
         if (ts.lds) {                                      // final values back into the image for the column pass
           *(float4*)(xt + row * LD + cc * 8) = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)(xt + row * LD + cc * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -669,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
   if (!ts.lds) __syncthreads();
   float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
-  conv_epilogue_rows<BNT, MT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
+  conv_epilogue_rows<BNT, MT, true>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
   tile_stats_flush(a, ts);
 }
 

@@ -34,13 +34,13 @@ class _EmbedArgs(C.Structure):
 
 class _LnArgs(C.Structure):
     _fields_ = [("x", _P), ("y", _P), ("x_bs", _I64), ("y_bs", _I64), ("out_bs", _I64), ("gamma", _P), ("beta", _P), ("eps", _F),
-                ("film", _P), ("film_stride", _I), ("B", _I), ("T", _I), ("E", _I), ("out", _P), ("out_hi", _P), ("out_hi_bs", _I64)]
+                ("film", _P), ("film_stride", _I), ("B", _I), ("T", _I), ("E", _I), ("out", _P), ("out_hi", _P), ("out_hi_bs", _I64), ("out_lo", _P)]
 
 
 class _AttnArgs(C.Structure):
     _fields_ = [("q", _P), ("k", _P), ("v", _P), ("q_bs", _I64), ("k_bs", _I64), ("v_bs", _I64), ("q_rs", _I), ("k_rs", _I),
                 ("v_rs", _I), ("B", _I), ("Tq", _I), ("Tk", _I), ("H", _I), ("hd", _I), ("mode", _I), ("scale", _F), ("out", _P),
-                ("out_rs", _I), ("out_hi", _P)]
+                ("out_rs", _I), ("out_hi", _P), ("out_lo", _P), ("split", _I)]
 
 
 _sigs_done = False
@@ -51,8 +51,8 @@ def _lib():
     lib = _unet_lib()
     if not _sigs_done:
         for name, argt in (("ctdd_hollow_embed", [_P, _P]), ("ctdd_hollow_layernorm", [_P, _P]),
-                           ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _P, _I64, _I, _I64, _P]),
-                           ("ctdd_hollow_put_rows", [_P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P]),
+                           ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _I64, _P]),
+                           ("ctdd_hollow_put_rows", [_P, _P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P]),
                            ("ctdd_hollow_attention_bf16", [_P, _P])):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argt, _I
@@ -73,10 +73,14 @@ def supports(model):
 class HollowEngine:
     def __init__(self, model, precision=None):
         self.model, self.net = model, model.net
-        self.precision = precision or getattr(model.net.config.model, "engine_precision", "fp32")
-        if self.precision not in ("fp32", "bf16"):
+        self.precision = precision or getattr(model.net.config.model, "engine_precision", "bf16x3")
+        if self.precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError(f"unknown engine precision {self.precision}")
-        self.fast = self.precision == "bf16"
+        # "fp32": exact-fp32 matrix instructions and fp32 FMA attention; "bf16": bf16 operands (~1e-3 absolute on the logits);
+        # "bf16x3": every GEMM / attention operand as a hi + lo bf16 pair, three bf16 products per contraction with fp32
+        # accumulation (x w ~ xh wh + xl wh + xh wl, dropped terms ~2^-17 relative): fp32-grade logits at bf16 matrix rates
+        self.fast = self.precision in ("bf16", "bf16x3")
+        self.split = self.precision == "bf16x3"
         self.dev = next(self.net.parameters()).device
         if self.dev.type != "cuda":
             raise native.CtddError("HollowEngine needs the model on a GPU")
@@ -98,8 +102,9 @@ class HollowEngine:
         st.t_in = torch.zeros((B,), dtype=torch.float32, device=dev)
         stream = lambda: torch.cuda.current_stream().cuda_stream
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        fast = self.fast
+        fast, split = self.fast, self.split
         hi = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev) if fast else None     # bf16 GEMM operands
+        lo = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev) if split else None    # their second terms
 
         def P(t):
             return None if t is None else t.data_ptr()
@@ -117,7 +122,7 @@ class HollowEngine:
             run.label, run.flops = (fn.__name__, label), flops
             plan.append(run)
 
-        def linear(x, rows, K, lin_w, lin_b, out, act=0, res=None, label="", x_hi=None, out_hi=None):
+        def linear(x, rows, K, lin_w, lin_b, out, act=0, res=None, label="", x_hi=None, out_hi=None, x_lo=None, out_lo=None):
             """out[rows][N] = act(x[rows][K] @ W^T + b) (+ res) on the implicit-GEMM kernel: fp32 operands, or bf16
             operands (x_hi, bf16 weights) when x_hi is given; out (fp32) and/or out_hi (bf16) receive the result."""
             w = W(lin_w)
@@ -127,16 +132,29 @@ class HollowEngine:
             a.nseg = 1
             a.seg[0].C, a.seg[0].kind = K, SEG_1x1
             use_bf16 = x_hi is not None
-            if use_bf16:
+            if split and use_bf16 and (N % 8 != 0 or x_lo is None):
+                assert x is not None, label                      # (a 3-column logits layer: the exact-fp32 kernel)
+                use_bf16 = False
+            if use_bf16 and split:
+                wh = w.to(torch.bfloat16)
+                wl = (w - wh.float()).to(torch.bfloat16)
+                wcat = torch.cat([wh, wh, wl], dim=1).contiguous()        # [N][3K] against the segments [x_hi | x_lo | x_hi]
+                keep.append(wcat)
+                a.nseg = 3
+                for si, xs in enumerate((x_hi, x_lo, x_hi)):
+                    a.seg[si].C, a.seg[si].kind, a.seg[si].hi = K, SEG_1x1, P(xs)
+                a.w_hi = P(wcat)
+            elif use_bf16:
                 wh = w.to(torch.bfloat16).contiguous()
                 keep.append(wh)
                 a.seg[0].hi, a.w_hi = P(x_hi), P(wh)
             else:
                 a.seg[0].f32, a.w_f32 = P(x), P(w)
-            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = 1, rows, 1, rows, 1, N, K
+            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = 1, rows, 1, rows, 1, N, K * a.nseg
             a.bias = P(W(lin_b)) if lin_b is not None else None
             a.res_f32 = P(res)
-            a.out_f32, a.out_hi, a.act = P(out), P(out_hi), act
+            a.out_f32, a.out_hi, a.act = P(out), P(out_hi) if use_bf16 or not split else None, act
+            a.out_lo = P(out_lo) if use_bf16 else None
             keep.append(a)
             if use_bf16:
                 bk = 96 if K % 96 == 0 else 64 if K % 64 == 0 else 32 if K % 32 == 0 else 16
@@ -160,25 +178,25 @@ class HollowEngine:
                     pbnt = 1
                 wm = 64 if (rows >= 256 * 256 and (pbk, pbnt) in ((48, 3), (48, 4), (64, 4), (64, 2), (48, 2))) else 32
                 launch(lib.ctdd_unet_conv_patch, C.byref(a), pbk, pbnt, wm, label=f"linear {label} {rows}x{K}->{N} patch",
-                       flops=2 * rows * K * N)
+                       flops=2 * rows * K * N * a.nseg)
                 return
             launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, 0 if use_bf16 else 1, label=f"linear {label} {rows}x{K}->{N}",
                    flops=2 * rows * K * N)
 
-        def layernorm(x, x_bs, T, Ed, norm, out, out_bs, y=None, y_bs=0, film=None, film_stride=0, out_hi=None, out_hi_bs=0):
+        def layernorm(x, x_bs, T, Ed, norm, out, out_bs, y=None, y_bs=0, film=None, film_stride=0, out_hi=None, out_hi_bs=0, out_lo=None):
             a = _LnArgs()
             a.x, a.y, a.x_bs, a.y_bs, a.out_bs = P(x), P(y), x_bs, y_bs, out_bs
             a.gamma, a.beta, a.eps = P(W(norm.weight)), P(W(norm.bias)), float(norm.eps)
             a.film, a.film_stride, a.B, a.T, a.E, a.out = P(film), film_stride, B, T, Ed, P(out)
-            a.out_hi, a.out_hi_bs = P(out_hi), out_hi_bs
+            a.out_hi, a.out_hi_bs, a.out_lo = P(out_hi), out_hi_bs, P(out_lo)
             keep.append(a)
             launch(lib.ctdd_hollow_layernorm, C.byref(a))
 
-        def attention(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, Tq, Tk, mode, out, out_hi=None):
+        def attention(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, Tq, Tk, mode, out, out_hi=None, out_lo=None):
             a = _AttnArgs()
             a.q, a.k, a.v, a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = q, k, v, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs
             a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale, a.out, a.out_rs = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd), P(out), E
-            a.out_hi = P(out_hi)
+            a.out_hi, a.out_lo, a.split = P(out_hi), P(out_lo), 1 if split else 0
             keep.append(a)
             fn = lib.ctdd_hollow_attention_bf16 if (fast and hd in (16, 32) and getattr(m, "engine_attention", "mfma") == "mfma") else lib.ctdd_hollow_attention
             launch(fn, C.byref(a), label=f"attention mode {mode} {Tq}x{Tk}")
@@ -202,41 +220,46 @@ class HollowEngine:
         # ---- the two causal stacks
         ln_buf, qkv, ctx, hid = (None if fast else f32(R, E)), f32(R, 3 * E), (None if fast else f32(R, E)), (None if fast else f32(R, mlp))
         ln_hi, ctx_hi, hid_hi = hi(R, E), hi(R, E), hi(R, mlp)
-        keep.extend([ln_buf, qkv, ctx, hid, ln_hi, ctx_hi, hid_hi])
+        ln_lo, ctx_lo, hid_lo = lo(R, E), lo(R, E), lo(R, mlp)
+        keep.extend([ln_buf, qkv, ctx, hid, ln_hi, ctx_hi, hid_hi, ln_lo, ctx_lo, hid_lo])
         for x, stack, mode in ((st.l2r, net.module_l2r, 0), (st.r2l, net.module_r2l, 1)):
             for blk in stack.trans_block_layers:
                 sa, ff = blk.self_attention_block, blk.feed_forward_block
                 mha = sa.self_attention
-                layernorm(x, D * E, D, E, sa.norm, ln_buf, D * E, out_hi=ln_hi, out_hi_bs=D * E)
-                linear(ln_buf, R, E, mha.in_proj_weight, mha.in_proj_bias, qkv, label="qkv", x_hi=ln_hi)
+                layernorm(x, D * E, D, E, sa.norm, ln_buf, D * E, out_hi=ln_hi, out_hi_bs=D * E, out_lo=ln_lo)
+                linear(ln_buf, R, E, mha.in_proj_weight, mha.in_proj_bias, qkv, label="qkv", x_hi=ln_hi, x_lo=ln_lo)
                 attention(P(qkv), D * 3 * E, 3 * E, P(qkv) + 4 * E, D * 3 * E, 3 * E, P(qkv) + 8 * E, D * 3 * E, 3 * E, D, D, mode, ctx,
-                          out_hi=ctx_hi)
-                linear(ctx, R, E, mha.out_proj.weight, mha.out_proj.bias, x, res=x, label="attn out", x_hi=ctx_hi)   # in place: + inputs
-                layernorm(x, D * E, D, E, ff.norm, ln_buf, D * E, out_hi=ln_hi, out_hi_bs=D * E)
-                linear(ln_buf, R, E, ff.mlp.fc1.weight, ff.mlp.fc1.bias, hid, act=1, label="fc1", x_hi=ln_hi, out_hi=hid_hi)
-                linear(hid, R, mlp, ff.mlp.fc2.weight, None, x, res=x, label="fc2", x_hi=hid_hi)
+                          out_hi=ctx_hi, out_lo=ctx_lo)
+                linear(ctx, R, E, mha.out_proj.weight, mha.out_proj.bias, x, res=x, label="attn out", x_hi=ctx_hi, x_lo=ctx_lo)   # in place: + inputs
+                layernorm(x, D * E, D, E, ff.norm, ln_buf, D * E, out_hi=ln_hi, out_hi_bs=D * E, out_lo=ln_lo)
+                linear(ln_buf, R, E, ff.mlp.fc1.weight, ff.mlp.fc1.bias, hid, act=1, label="fc1", x_hi=ln_hi, x_lo=ln_lo, out_hi=hid_hi,
+                       out_lo=hid_lo)
+                linear(hid, R, mlp, ff.mlp.fc2.weight, None, x, res=x, label="fc2", x_hi=hid_hi, x_lo=hid_lo)
 
         # ---- attention readout
         ro = net.readout_module
         ca = ro.cross_attention
         Tk = 2 * D + 1
-        allk, allk_hi = f32(B, Tk, E), hi(B, Tk, E)
-        keep.extend([allk, allk_hi])
-        launch(lib.ctdd_hollow_put_rows, P(st.temb), P(allk), P(allk_hi), Tk * E, B, E)
-        layernorm(st.l2r, D * E, D, E, ro.ln1, allk[:, 1:], Tk * E, out_hi=None if not fast else allk_hi[:, 1:], out_hi_bs=Tk * E)
-        layernorm(st.r2l, D * E, D, E, ro.ln2, allk[:, D + 1:], Tk * E, out_hi=None if not fast else allk_hi[:, D + 1:], out_hi_bs=Tk * E)
-        qin, qin_hi, raw = (None if fast else f32(R, E)), hi(R, E), f32(R, E)
-        launch(lib.ctdd_hollow_add, P(allk) + 4 * E, Tk * E, P(allk) + 4 * (D + 1) * E, Tk * E, P(qin), P(qin_hi), D * E, B, D * E)
-        launch(lib.ctdd_hollow_add, P(st.l2r), D * E, P(st.r2l), D * E, P(raw), None, D * E, B, D * E)
+        allk, allk_hi, allk_lo = f32(B, Tk, E), hi(B, Tk, E), lo(B, Tk, E)
+        keep.extend([allk, allk_hi, allk_lo])
+        launch(lib.ctdd_hollow_put_rows, P(st.temb), P(allk), P(allk_hi), P(allk_lo), Tk * E, B, E)
+        layernorm(st.l2r, D * E, D, E, ro.ln1, allk[:, 1:], Tk * E, out_hi=None if not fast else allk_hi[:, 1:], out_hi_bs=Tk * E,
+                  out_lo=None if not split else allk_lo[:, 1:])
+        layernorm(st.r2l, D * E, D, E, ro.ln2, allk[:, D + 1:], Tk * E, out_hi=None if not fast else allk_hi[:, D + 1:], out_hi_bs=Tk * E,
+                  out_lo=None if not split else allk_lo[:, D + 1:])
+        qin, qin_hi, qin_lo, raw = (None if fast else f32(R, E)), hi(R, E), lo(R, E), f32(R, E)
+        launch(lib.ctdd_hollow_add, P(allk) + 4 * E, Tk * E, P(allk) + 4 * (D + 1) * E, Tk * E, P(qin), P(qin_hi), P(qin_lo), D * E, B, D * E)
+        launch(lib.ctdd_hollow_add, P(st.l2r), D * E, P(st.r2l), D * E, P(raw), None, None, D * E, B, D * E)
         qb, kb, vb = f32(R, E), f32(B * Tk, E), f32(B * Tk, E)
-        keep.extend([qin, qin_hi, raw, qb, kb, vb])
-        linear(qin, R, E, ca.dense_query.weight, None, qb, label="readout q", x_hi=qin_hi)
-        linear(allk, B * Tk, E, ca.dense_key.weight, ca.dense_key.bias, kb, label="readout k", x_hi=allk_hi)
-        linear(allk, B * Tk, E, ca.dense_val.weight, ca.dense_val.bias, vb, label="readout v", x_hi=allk_hi)
-        attention(P(qb), D * E, E, P(kb), Tk * E, E, P(vb), Tk * E, E, D, Tk, 2, ctx, out_hi=ctx_hi)
-        xr, xr_hi = (None if fast else f32(R, E)), hi(R, E)
-        keep.extend([xr, xr_hi])
-        linear(ctx, R, E, ca.out_linear.weight, ca.out_linear.bias, xr, res=raw, label="readout out", x_hi=ctx_hi, out_hi=xr_hi)
+        keep.extend([qin, qin_hi, qin_lo, raw, qb, kb, vb])
+        linear(qin, R, E, ca.dense_query.weight, None, qb, label="readout q", x_hi=qin_hi, x_lo=qin_lo)
+        linear(allk, B * Tk, E, ca.dense_key.weight, ca.dense_key.bias, kb, label="readout k", x_hi=allk_hi, x_lo=allk_lo)
+        linear(allk, B * Tk, E, ca.dense_val.weight, ca.dense_val.bias, vb, label="readout v", x_hi=allk_hi, x_lo=allk_lo)
+        attention(P(qb), D * E, E, P(kb), Tk * E, E, P(vb), Tk * E, E, D, Tk, 2, ctx, out_hi=ctx_hi, out_lo=ctx_lo)
+        xr, xr_hi, xr_lo = (None if fast else f32(R, E)), hi(R, E), lo(R, E)
+        keep.extend([xr, xr_hi, xr_lo])
+        linear(ctx, R, E, ca.out_linear.weight, ca.out_linear.bias, xr, res=raw, label="readout out", x_hi=ctx_hi, x_lo=ctx_lo, out_hi=xr_hi,
+               out_lo=xr_lo)
 
         # ---- FiLM residual readout
         rr = ro.model
@@ -246,20 +269,20 @@ class HollowEngine:
         linear(st.temb, B, E, lin[0].weight, lin[0].bias, tm_h, act=2, label="temb mlp 1")
         linear(tm_h, B, mlp, lin[1].weight, lin[1].bias, tm, label="temb mlp 2")
         h, r, rh = f32(R, E2), f32(R, E2), (None if fast else f32(R, mlp))
-        h_hi, rh_hi = hi(R, E2), hi(R, mlp)
-        keep.extend([tm_h, tm, h, r, rh, h_hi, rh_hi])
-        linear(xr, R, E, rr.input_layer.weight, rr.input_layer.bias, h, label="readout in", x_hi=xr_hi, out_hi=h_hi)
+        h_hi, rh_hi, h_lo, rh_lo = hi(R, E2), hi(R, mlp), lo(R, E2), lo(R, mlp)
+        keep.extend([tm_h, tm, h, r, rh, h_hi, rh_hi, h_lo, rh_lo])
+        linear(xr, R, E, rr.input_layer.weight, rr.input_layer.bias, h, label="readout in", x_hi=xr_hi, x_lo=xr_lo, out_hi=h_hi, out_lo=h_lo)
         for i in range(rr.n_res):
             mlp_i, ln_i = rr.resid_layers[2 * i], rr.resid_layers[2 * i + 1]
             li = [l for l in mlp_i.layers if isinstance(l, torch.nn.Linear)]
-            linear(h, R, E2, li[0].weight, li[0].bias, rh, act=2, label="resid 1", x_hi=h_hi, out_hi=rh_hi)
-            linear(rh, R, mlp, li[1].weight, li[1].bias, r, label="resid 2", x_hi=rh_hi)
+            linear(h, R, E2, li[0].weight, li[0].bias, rh, act=2, label="resid 1", x_hi=h_hi, x_lo=h_lo, out_hi=rh_hi, out_lo=rh_lo)
+            linear(rh, R, mlp, li[1].weight, li[1].bias, r, label="resid 2", x_hi=rh_hi, x_lo=rh_lo)
             fl = f32(B, 4 * E)
             keep.append(fl)
             linear(tm, B, 4 * E, rr.film_layer[i].weight, rr.film_layer[i].bias, fl, label="film")          # per-sample path: fp32
-            layernorm(h, D * E2, D, E2, ln_i, h, D * E2, y=r, y_bs=D * E2, film=fl, film_stride=4 * E, out_hi=h_hi, out_hi_bs=D * E2)
+            layernorm(h, D * E2, D, E2, ln_i, h, D * E2, y=r, y_bs=D * E2, film=fl, film_stride=4 * E, out_hi=h_hi, out_hi_bs=D * E2, out_lo=h_lo)
         st.logits = f32(B, D, rr.out_dim)
-        linear(h, R, E2, rr.logits_layer.weight, rr.logits_layer.bias, st.logits, label="logits", x_hi=h_hi)
+        linear(h, R, E2, rr.logits_layer.weight, rr.logits_layer.bias, st.logits, label="logits", x_hi=h_hi, x_lo=h_lo)
         st.plan, st.keep, st.graph = plan, keep, None
         return st
 

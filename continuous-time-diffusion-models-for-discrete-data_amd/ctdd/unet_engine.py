@@ -32,7 +32,7 @@ class _ConvArgs(C.Structure):
     _fields_ = [("seg", _Seg * 3), ("nseg", _I), ("w_hi", _P), ("w_f32", _P), ("B", _I), ("H", _I), ("W", _I),
                 ("Hin", _I), ("Win", _I), ("N", _I), ("Ktot", _I), ("bias", _P), ("tbias", _P), ("tb_stride", _I),
                 ("res_f32", _P), ("res_bf16", _P), ("out_f32", _P), ("out_hi", _P), ("stats", _P), ("logits_C", _I),
-                ("ksplit", _I), ("acc_buf", _P), ("act", _I)]
+                ("ksplit", _I), ("acc_buf", _P), ("act", _I), ("out_lo", _P)]
 
 
 class _FirstArgs(C.Structure):

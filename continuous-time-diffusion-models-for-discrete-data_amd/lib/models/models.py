@@ -121,9 +121,10 @@ class HollowTransformer(nn.Module):
         if self._use_engine(x):
             from ctdd import hollow_engine
             if self._engine is None:
-                # cfg.model.engine_precision = "bf16": bf16 matrix-core GEMMs and attention (fp32 accumulation / softmax /
-                # LayerNorm), ~3.4x the fp32 forward rate at ~1e-3 absolute logit error; default "fp32" holds the 1e-4 bar
-                self._engine = hollow_engine.HollowEngine(self, precision=getattr(self.cfg.model, "engine_precision", "fp32"))
+                # cfg.model.engine_precision: "bf16x3" (default; hi + lo bf16 operand pairs, three matrix-core products per
+                # contraction: ~1e-5 of the logit range from the fp32 module, 2.3x its speed), "fp32" (exact-fp32 matrix
+                # instructions, ~2e-6), "bf16" (single bf16 operands: ~5e-3, 3.4x)
+                self._engine = hollow_engine.HollowEngine(self, precision=getattr(self.cfg.model, "engine_precision", None))
             return self._engine(x, times)
         return self.net(x, times)
 

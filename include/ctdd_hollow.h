@@ -26,12 +26,15 @@ typedef struct {
   const float* x; const float* y; int64_t x_bs, y_bs, out_bs; const float* gamma; const float* beta; float eps;
   const float* film; int film_stride; int B, T, E; float* out;
   void* out_bf16; int64_t out_bf16_bs;            /* optional bf16 copy of the output (GEMM operand of the bf16 mode) */
+  void* out_lo;                                   /* optional second bf16 term bf16(out - out_bf16), stride out_bf16_bs: out ~ hi + lo
+                                                   * to 2^-17 (operands of the split mode: three bf16 products per GEMM) */
 } ctdd_hollow_ln_args;
 int ctdd_hollow_layernorm(const void* ln_args, void* stream);
 
-int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, int64_t out_bs, int B,
-                    int64_t per_batch, void* stream);                                   /* l2r + r2l (fp32 and/or bf16 result) */
-int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, int64_t dst_bs, int B, int E, void* stream);   /* temb into key slot 0 */
+int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, void* out_lo, int64_t out_bs,
+                    int B, int64_t per_batch, void* stream);                            /* l2r + r2l (fp32 and/or bf16 hi (+ lo) result) */
+int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, void* dst_lo, int64_t dst_bs, int B, int E,
+                         void* stream);                                                 /* temb into key slot 0 */
 
 /* masked multi-head attention, softmax(scale q.k) v: mode 0 causal (j <= i, UniDirectionalTransformer l2r 534-560),
  * 1 anti-causal (j >= i, r2l), 2 readout over [temb | l2r | r2l] with Tk = 2 Tq + 1 (CrossAttention 204-280).
@@ -40,6 +43,9 @@ typedef struct {
   const float* q; const float* k; const float* v; int64_t q_bs, k_bs, v_bs; int q_rs, k_rs, v_rs;
   int B, Tq, Tk, H, hd, mode; float scale; float* out; int out_rs;
   void* out_bf16;                                 /* optional bf16 copy of the output */
+  void* out_lo;                                   /* optional second bf16 term of the output */
+  int split;                                      /* ctdd_hollow_attention_bf16: 1 = q, k, v and the probabilities enter as hi + lo bf16
+                                                   * pairs, three products per contraction (~1e-5 relative instead of ~4e-3) */
 } ctdd_hollow_attn_args;
 int ctdd_hollow_attention(const void* attn_args, void* stream);
 /* same contract with both products on the bf16 matrix cores (fp32 softmax); head dimension 16 or 32 */

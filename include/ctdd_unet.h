@@ -30,7 +30,8 @@ typedef struct {
   const float* res_f32; const void* res_bf16;
   float* out_f32; void* out_hi; double* stats; int logits_C;   /* stats: [B][N][2] fp64 sum / sum of squares */
   int ksplit; float* acc_buf;                                  /* split-K: zeroed [M][N] fp32 partial-sum buffer */
-  int act;                                                     /* ctdd_unet_conv only: 0 none, 1 ReLU, 2 GELU(erf) on acc + bias, before the residual */
+  int act;                                                     /* 0 none, 1 ReLU, 2 GELU(erf) on acc + bias, before the residual (not in res / ring) */
+  void* out_lo;                                                /* ctdd_unet_conv_patch: optional bf16(out - out_hi), the second term of a split operand */
 } ctdd_conv_args;
 /* out = conv(segments) + bias + tbias[b] + residual; bk in {96,64,32,16}, bnt = N-tile/32,
  * f32 = 0: bf16 MFMA, 1: exact-fp32 MFMA */

@@ -39,10 +39,13 @@ def test_hollow_engine_matches_reference_golden(golden, tag):
     cfg, model, x, t, ref = _tiny(golden, tag)
     assert supports(model)
     with torch.no_grad():
-        out = HollowEngine(model)(x.long(), t).cpu().numpy()
+        out = HollowEngine(model, precision="fp32")(x.long(), t).cpu().numpy()
         via_model = model(x.long(), t).cpu().numpy()                # the wrapper routes eval/no_grad calls to the engine
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-4)         # BASELINE bar
-    np.testing.assert_array_equal(via_model, out)
+    with torch.no_grad():
+        split = HollowEngine(model, precision="bf16x3")(x.long(), t).cpu().numpy()
+    np.testing.assert_allclose(split, ref, rtol=0, atol=1e-4)       # same bar for the hi/lo bf16 mode (the wrapper's default)
+    np.testing.assert_array_equal(via_model, split)
     model.train()
 
 
@@ -62,10 +65,13 @@ def test_hollow_engine_matches_module_maze():
     with torch.no_grad():
         cfg.model.engine = "torch"
         ref = model(x, t).cpu()
-        out = HollowEngine(model)(x, t).cpu()
+        out = HollowEngine(model, precision="fp32")(x, t).cpu()
         fast = HollowEngine(model, precision="bf16")(x, t).cpu()
+        split = HollowEngine(model, precision="bf16x3")(x, t).cpu()
     assert ref.shape == out.shape == (5, 225, 3)
     assert (out - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0)
+    # three bf16 products per contraction (hi/lo operand pairs): the fp32 bar
+    assert (split - ref).abs().max().item() < 2e-4 * max(ref.abs().max().item(), 1.0)
     # bf16 GEMM operands (throughput mode): reported separately, looser bar
     assert (fast - ref).abs().max().item() < 5e-2 * max(ref.abs().max().item(), 1.0)
     model.train()
@@ -75,7 +81,7 @@ def test_hollow_engine_matches_module_maze():
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_attention_kernels_against_masked_softmax(hd, mode):
     """Both attention kernels (fp32 FMA; bf16 matrix cores) against a torch masked softmax, through the C ABI.
-    Ragged length (T = 197: 128 + 69, chunks of 32 with a 5-key tail).  fp32: 2e-5; bf16 operands: 2e-2."""
+    Ragged length (T = 197: 128 + 69, chunks of 32 with a 5-key tail).  fp32: 2e-5; bf16 operands: 2e-2; hi/lo bf16 pairs (three products): 5e-5."""
     import ctypes as C
     from ctdd.hollow_engine import _AttnArgs, _lib
     lib = _lib()
@@ -99,10 +105,13 @@ def test_attention_kernels_against_masked_softmax(hd, mode):
     s = s.masked_fill(~ok, float("-inf"))
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, E).float()
     st = torch.cuda.current_stream().cuda_stream
-    for fn, tol in ((lib.ctdd_hollow_attention, 2e-5), (lib.ctdd_hollow_attention_bf16, 2e-2)):
+    for fn, tol, split in ((lib.ctdd_hollow_attention, 2e-5, 0), (lib.ctdd_hollow_attention_bf16, 2e-2, 0),
+                           (lib.ctdd_hollow_attention_bf16, 5e-5, 1)):
         out = torch.full((B, Tq, E), float("nan"), device="cuda")
         out_hi = torch.zeros(B, Tq, E, device="cuda", dtype=torch.bfloat16)
+        out_lo = torch.zeros(B, Tq, E, device="cuda", dtype=torch.bfloat16)
         a = _AttnArgs()
+        a.split, a.out_lo = split, out_lo.data_ptr()
         a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
         a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
         a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / hd ** 0.5
@@ -111,3 +120,5 @@ def test_attention_kernels_against_masked_softmax(hd, mode):
         torch.cuda.synchronize()
         assert (out - ref).abs().max().item() < tol, fn
         assert (out_hi.float() - ref).abs().max().item() < max(tol, 2e-2), fn
+        if fn is lib.ctdd_hollow_attention_bf16:
+            assert (out_hi.float() + out_lo.float() - out).abs().max().item() < 1e-4       # hi + lo ~ fp32 value (2^-17 relative)
