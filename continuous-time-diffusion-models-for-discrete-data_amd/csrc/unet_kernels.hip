@@ -171,7 +171,7 @@ __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, 
 // Each lane keeps its piece's column sums / sums of squares in fp32 over the <= 8 rows it visits per
 // sample and adds them to the workgroup's fp64 LDS statistics.
 // xt = this wave's [32][32*BNT + 4] fp32 region; rows wrow0 .. wrow0 + 32*MT of the output.
-template <int BNT, int MT, bool LO = false>
+template <int BNT, int MT, bool EXT = false>   // EXT: activation + second bf16 output term (the plain-GEMM users); compiled out of the U-Net kernels
 __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const ConvArgs& a, const f32x16 (&acc)[MT][BNT], float* xt, int64_t wrow0, int n0,
                                           int64_t M, int HW, const TileStats& ts, unsigned long long* epi_t = nullptr) {
 #ifdef CTDD_RES_STAMPS
@@ -186,11 +186,11 @@ __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const C
   // (260 scalar loads, each followed by a wait, in this unrolled epilogue).  Pin the integer fields in scalar registers.
   auto pin32 = [](int v) { asm volatile("" : "+s"(v)); return v; };
   const int aN = pin32(a.N), aB = pin32(a.B), a_tbs = pin32(a.tb_stride), a_lc = pin32(a.logits_C);
-  const int a_act = pin32(a.act);
+  const int a_act = EXT ? pin32(a.act) : 0;
   // (pointers stay as they are: laundering them through an integer loses the global address space -> flat_load/flat_store)
   float* const p_out_f32 = a.out_f32;
   unsigned short* const p_out_hi = a.out_hi;
-  unsigned short* const p_out_lo = LO ? a.out_lo : nullptr;   // (second bf16 term: the patch kernel only)
+  unsigned short* const p_out_lo = EXT ? a.out_lo : nullptr;
   const unsigned short* const p_res_bf16 = a.res_bf16;
   const float* const p_res_f32 = a.res_f32;
   const float* const p_tbias = a.tbias;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
 // (double-buffered, one barrier per tap).  The next slab is prefetched into registers under the
 // last taps.  4 waves, each WM rows x (32*BNT) columns; grid.z splits the channel chunks when M
 // is too small to fill the chip (7x7 levels), partial sums meet in acc_buf.
-template <int BK, int BNT, int WM>
+template <int BK, int BNT, int WM, bool EXT = false>
 __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   constexpr int BN = 32 * BNT, BMP = 4 * WM, MT = WM / 32;
   constexpr int LDK = BK + 8, VPR = BK / 8;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
   if (!ts.lds) __syncthreads();
   float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
-  conv_epilogue_rows<BNT, MT, true>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
+  conv_epilogue_rows<BNT, MT, EXT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
   tile_stats_flush(a, ts);
 }
 
@@ -1655,7 +1655,7 @@ extern "C" int ctdd_unet_conv(const void* args_, int bk, int bnt, int f32, void*
   CTDD_REQUIRE(false, CTDD_ERANGE, "no conv instantiation for BK=%d BNT=%d", bk, bnt);
 }
 
-template <int BK, int BNT, int WM>
+template <int BK, int BNT, int WM, bool EXT = false>
 static int launch_patch(const ConvArgs& a, hipStream_t st) {
   constexpr int LDK = BK + 8;
   const int PR = 4 * WM + 2 * (a.W + 1);
@@ -1666,10 +1666,10 @@ static int launch_patch(const ConvArgs& a, hipStream_t st) {
   dim3 g((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), a.ksplit > 1 ? a.ksplit : 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_conv_patch<BK, BNT, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_conv_patch<BK, BNT, WM, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM>), g, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM, EXT>), g, dim3(256), lds, st, a);
   if (int rc = finish_launch("k_conv_patch")) return rc;
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
@@ -1692,6 +1692,12 @@ extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, 
   }
   CTDD_REQUIRE(a.ksplit <= 1 || (a.acc_buf && a.logits_C == 0), CTDD_EINVAL, "split-K needs acc_buf");
   hipStream_t st = (hipStream_t)stream;
+  if (a.act != 0 || a.out_lo) {                 // plain-GEMM use (hollow transformer linears): activation / hi + lo outputs
+#define CASEX(BK_, BNT_) if (bk == BK_ && bnt == BNT_ && wm == 32) return launch_patch<BK_, BNT_, 32, true>(a, st);
+    CASEX(64, 4) CASEX(64, 2) CASEX(64, 1) CASEX(48, 4) CASEX(48, 3) CASEX(48, 2) CASEX(48, 1) CASEX(32, 4) CASEX(32, 3) CASEX(32, 1) CASEX(16, 1)
+#undef CASEX
+    CTDD_REQUIRE(false, CTDD_ERANGE, "no patch-conv instantiation with activation / split output for BK=%d BNT=%d WM=%d (wm must be 32)", bk, bnt, wm);
+  }
 #define CASEP(BK_, BNT_, WM_) if (bk == BK_ && bnt == BNT_ && wm == WM_) return launch_patch<BK_, BNT_, WM_>(a, st);
   CASEP(48, 3, 64) CASEP(48, 3, 32) CASEP(48, 4, 64) CASEP(48, 4, 32)
   CASEP(64, 4, 64) CASEP(64, 4, 32) CASEP(64, 2, 64) CASEP(64, 2, 32) CASEP(32, 1, 32) CASEP(32, 3, 32) CASEP(32, 4, 32)

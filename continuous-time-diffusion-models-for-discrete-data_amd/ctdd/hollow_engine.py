@@ -176,7 +176,8 @@ class HollowEngine:
                     pbnt = 4 if N % 128 == 0 else 3 if N > 32 else 1
                 else:
                     pbnt = 1
-                wm = 64 if (rows >= 256 * 256 and (pbk, pbnt) in ((48, 3), (48, 4), (64, 4), (64, 2), (48, 2))) else 32
+                ext = act != 0 or a.out_lo                 # activation / hi + lo outputs: the EXT instantiations (wm = 32)
+                wm = 64 if (not ext and rows >= 256 * 256 and (pbk, pbnt) in ((48, 3), (48, 4), (64, 4), (64, 2), (48, 2))) else 32
                 launch(lib.ctdd_unet_conv_patch, C.byref(a), pbk, pbnt, wm, label=f"linear {label} {rows}x{K}->{N} patch",
                        flops=2 * rows * K * N * a.nseg)
                 return
