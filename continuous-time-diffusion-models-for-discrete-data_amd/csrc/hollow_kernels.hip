@@ -1,14 +1,16 @@
 // hollow_kernels.hip -- inference kernels of the SDDM hollow (bidirectional-causal) transformer
 // (reference lib/networks/hollow_networks.py: BidirectionalTransformer2 668-755, UniDirectionalTransformer
 // 497-568, SelfAttentionBlock 311-340, CrossAttention 204-280, AttentionReadout 283-308,
-// ResidualReadout 90-132, PositionalEncoding 1136-1156).  fp32 throughout (the 1e-4 logit parity bar).
-// The linear layers run on the generic fp32-MFMA implicit-GEMM kernel of unet_kernels.hip (a token is a
-// "pixel", the weight a 1x1 segment; ReLU / GELU in its epilogue); this file holds what is not a GEMM:
-//   k_hollow_embed     state -> the two shifted token sequences [temb | x_0..x_{D-2}] and [x_1..x_{D-1} | temb]
-//   k_hollow_layernorm LayerNorm of (x [+ y]) with optional per-sample FiLM, strided destination
-//   k_hollow_add       a + b over strided batches (l2r + r2l)
-//   k_hollow_attention masked multi-head attention with an online softmax: causal (j <= i), anti-causal
-//                      (j >= i) and the readout mask [temb | l2r j <= i | r2l j >= i]
+// ResidualReadout 90-132, PositionalEncoding 1136-1156).
+// The linear layers run on the GEMM kernels of unet_kernels.hip (a token is a "pixel", the weight a 1x1 segment; ReLU /
+// GELU in the epilogue): the exact-fp32 matrix kernel in the fp32 mode, the bf16 slab kernel in the bf16 and bf16x3 modes
+// (bf16x3: operands as hi + lo bf16 pairs, three products per contraction).  This file holds what is not a GEMM:
+//   k_hollow_embed          state -> the two shifted token sequences [temb | x_0..x_{D-2}] and [x_1..x_{D-1} | temb]
+//   k_hollow_layernorm      LayerNorm of (x [+ y]) with optional per-sample FiLM, strided destination, fp32 / bf16 hi (+ lo) outputs
+//   k_hollow_add            a + b over strided batches (l2r + r2l)
+//   k_hollow_attention      fp32 masked multi-head attention with an online softmax: causal (j <= i), anti-causal
+//                           (j >= i) and the readout mask [temb | l2r j <= i | r2l j >= i]
+//   k_hollow_attention_mfma the same on the bf16 matrix cores (single or hi + lo operands), fp32 softmax
 #include "common.hpp"
 
 namespace ctdd {
