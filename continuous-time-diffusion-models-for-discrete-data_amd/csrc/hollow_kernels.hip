@@ -357,15 +357,25 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
     }
     // ---- mask + online softmax for the lane's query over its 16 keys (+ the partner lane's 16)
     float mx = -INFINITY;
+    // chunks every query of the wave sees in full need no per-element mask (most of a causal triangle); wave-uniform
+    bool full = q0 + 31 < a.Tq && j0 + 31 < a.Tk;
+    if (a.mode == 0) full = full && j0 + 31 <= q0;
+    else if (a.mode == 1) full = full && j0 >= q0 + 31;
+    else full = full && ((j0 >= 1 && j0 + 31 <= a.Tq && j0 + 30 <= q0) || (j0 > a.Tq && j0 - a.Tq - 1 >= q0 + 31));
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      bool ok = qok && j < a.Tk;
-      if (a.mode == 0) ok = ok && j <= i;
-      else if (a.mode == 1) ok = ok && j >= i;
-      else ok = ok && (j == 0 || (j <= a.Tq ? j - 1 <= i : j - a.Tq - 1 >= i));
-      sacc[r] = ok ? sacc[r] : -INFINITY;
-      mx = fmaxf(mx, sacc[r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        bool ok = qok && j < a.Tk;
+        if (a.mode == 0) ok = ok && j <= i;
+        else if (a.mode == 1) ok = ok && j >= i;
+        else ok = ok && (j == 0 || (j <= a.Tq ? j - 1 <= i : j - a.Tq - 1 >= i));
+        sacc[r] = ok ? sacc[r] : -INFINITY;
+        mx = fmaxf(mx, sacc[r]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
     const float mn = fmaxf(m, mx);
