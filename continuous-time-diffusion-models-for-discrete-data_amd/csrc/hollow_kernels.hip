@@ -307,24 +307,40 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
   for (int idx = threadIdx.x; idx < NT * 32 * VLD / 2; idx += 256) ((unsigned*)&Vsm[0][0])[idx] = 0u;   // (rows >= HD stay zero)
   const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tq) - 1;            // query range of the workgroup
   const int mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;                          // ... of this wave
-  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
-    const int j1 = min(j0 + 32, a.Tk) - 1;
-    auto range_any = [&](int lo, int hi) {
-      if (hi < lo) return false;
-      if (a.mode == 0) return j0 <= hi;
-      if (a.mode == 1) return j1 >= lo;
-      return j0 == 0 || (j0 <= a.Tq && j0 - 1 <= hi) || (j1 > a.Tq && j1 - a.Tq - 1 >= lo);
-    };
-    if (!range_any(wlo, whi)) continue;                                        // (uniform over the workgroup)
+  // chunk c (32 keys from jc) concerns the query range [lo, hi] iff some (query, key) pair is allowed
+  auto range_any = [&](int jc, int lo, int hi) {
+    const int jl = min(jc + 32, a.Tk) - 1;
+    if (hi < lo) return false;
+    if (a.mode == 0) return jc <= hi;
+    if (a.mode == 1) return jl >= lo;
+    return jc == 0 || (jc <= a.Tq && jc - 1 <= hi) || (jl > a.Tq && jl - a.Tq - 1 >= lo);
+  };
+  auto next_visible = [&](int jc) {                                            // (uniform over the workgroup)
+    while (jc < a.Tk && !range_any(jc, wlo, whi)) jc += 32;
+    return jc;
+  };
+  // one (K, V) float4 pair per thread and chunk, fetched a chunk ahead: the loads fly under the previous chunk's products
+  const bool stager = threadIdx.x < 32 * HD / 4;
+  const int sjj = threadIdx.x / (HD / 4), sc4 = (threadIdx.x % (HD / 4)) * 4;
+  float4 pk = make_float4(0.f, 0.f, 0.f, 0.f), pv = pk;
+  auto fetch = [&](int jc) {
+    const int j = jc + sjj;
+    pk = make_float4(0.f, 0.f, 0.f, 0.f);
+    pv = pk;
+    if (stager && j < a.Tk) {
+      pk = *(const float4*)(a.k + (size_t)b * a.k_bs + (size_t)j * a.k_rs + h * HD + sc4);
+      pv = *(const float4*)(a.v + (size_t)b * a.v_bs + (size_t)j * a.v_rs + h * HD + sc4);
+    }
+  };
+  int jnext = next_visible(0);
+  if (jnext < a.Tk) fetch(jnext);
+  while (jnext < a.Tk) {
+    const int j0 = jnext;
     __syncthreads();
     // stage the chunk: K rows as they are, V transposed, fp32 -> bf16 (hi, and the remainder lo in the split mode)
-    for (int idx = threadIdx.x; idx < 32 * HD / 4; idx += 256) {
-      const int jj = idx / (HD / 4), c4 = (idx % (HD / 4)) * 4, j = j0 + jj;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (j < a.Tk) {
-        kv = *(const float4*)(a.k + (size_t)b * a.k_bs + (size_t)j * a.k_rs + h * HD + c4);
-        vv = *(const float4*)(a.v + (size_t)b * a.v_bs + (size_t)j * a.v_rs + h * HD + c4);
-      }
+    if (stager) {
+      const int jj = sjj, c4 = sc4;
+      const float4 kv = pk, vv = pv;
       const unsigned k01 = hk_pack2(kv.x, kv.y), k23 = hk_pack2(kv.z, kv.w);
       *(uint2*)(&Ksm[0][jj * KLD + c4]) = make_uint2(k01, k23);
       const float ve[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -340,7 +356,9 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
       }
     }
     __syncthreads();
-    if (!range_any(mylo, myhi)) continue;                                      // (wave-uniform; no barrier below)
+    jnext = next_visible(j0 + 32);
+    if (jnext < a.Tk) fetch(jnext);
+    if (!range_any(j0, mylo, myhi)) continue;                                  // (wave-uniform; no barrier below)
     // ---- S^T = K Q^T : A = K rows (lane = key col, 8 dims per half), B = Q^T fragments
     f32x16 sacc;
 #pragma unroll
