@@ -19,10 +19,15 @@ def _maybe_ddp(net, cfg, rank):
     """cfg.distributed: minibatch-sharded data parallelism, one gradient all-reduce per step (RCCL on GPUs)."""
     if not cfg.distributed:
         return net
-    on_gpu = next(net.parameters()).is_cuda
+    dev = next(net.parameters()).device
+    on_gpu = dev.type == "cuda"
     # find_unused_parameters: the hollow network carries two sub-modules its forward never uses (`embedding`, `temb_net`,
     # hollow_networks.py:690-712); without the flag their bucket never reduces and the second step raises
-    return DDP(net, device_ids=[rank] if on_gpu else None, find_unused_parameters=True)
+    # (the reference passes device_ids=[rank]; the device the parameters live on is the same thing on one node with one
+    # process per GPU, and stays right when ranks and device indices differ -- several nodes, or ranks sharing a GPU)
+    unused = net.__class__.__name__ == "BidirectionalTransformer2" or bool(getattr(cfg, "ddp_find_unused_parameters", False))
+    return DDP(net, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()] if on_gpu else None,
+               find_unused_parameters=unused)
 
 
 def logistic_logits(mu, log_scale, S, fix_logistic, eps=1e-6):
