@@ -289,7 +289,7 @@ class UNetEngine:
             a.gamma, a.beta = ptr(g), ptr(b_)
             a.B, a.HW, a.G, a.eps, a.swish = B, HW, norm.num_groups, eps, int(swish)
             a.out_hi, a.out_f32 = ptr(out.hi), ptr(out.f32)
-            launch(lib.ctdd_unet_gn_apply, C.byref(a))
+            launch(lib.ctdd_unet_gn_apply, C.byref(a), label=f"gn {srcs[0].H}x{srcs[0].W} C={Ct} ({len(srcs)} src)")
             return out
 
         # ---- time embedding + all ResBlock projections in two launches
