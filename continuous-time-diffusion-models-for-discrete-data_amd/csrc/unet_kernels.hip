@@ -1278,50 +1278,66 @@ struct FirstConvArgs {
   float* out_f32; unsigned short* out_hi; double* stats;
   float* x0_f32;              // optional centred input (B,Cin,H,W) fp32 (logistic head needs it)
 };
+// The centred input rows a workgroup needs are converted once into an LDS slab with a zero border (no bounds tests and no
+// int -> float / division work in the tap loop); statistics leave a thread as fp32 sums over its <= ~8 pixels, meet in LDS
+// as plain stores, and one thread per (channel, moment) adds them up in fp64: one global atomic each, no LDS atomics.
+__host__ __device__ inline int first_conv_rows(int HW, int W, int gx) { return ((HW + gx - 1) / gx + W - 1) / W + 3; }
 template <int CIN>
 __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double sred[];     // [Cout][2] per-workgroup partial statistics
-  const int cg = a.Cout / 8, HW = a.H * a.W, b = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) sred[i] = 0.0;
-  __syncthreads();
-  // thread -> fixed channel group c8 and a strided set of this workgroup's pixels, so the
-  // statistics accumulate in registers and reach LDS once per thread
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int cg = a.Cout / 8, HW = a.H * a.W, b = blockIdx.y, Wp = a.W + 2;
   const int lanes = 256 / cg;                                         // pixel lanes per workgroup
   const int c8 = threadIdx.x % cg, pl = threadIdx.x / cg;
   const int per = (HW + gridDim.x - 1) / gridDim.x;
   const int p_lo = blockIdx.x * per, p_hi = min(p_lo + per, HW);
+  const int nrows_max = first_conv_rows(HW, a.W, gridDim.x);
+  float* slab = fsm;                                                   // [CIN][nrows_max][W + 2]
+  float* part = fsm + CIN * nrows_max * Wp;                            // [lanes][Cout][2]
+  if (p_lo >= p_hi) return;                                            // (uniform)
+  const int y_lo = p_lo / a.W, y_hi = (p_hi - 1) / a.W, nrows = y_hi - y_lo + 3;
+  for (int idx = threadIdx.x; idx < CIN * nrows * Wp; idx += 256) {
+    const int ci = idx / (nrows * Wp), rem = idx % (nrows * Wp), ry = rem / Wp, xc = rem % Wp;
+    const int yy = y_lo - 1 + ry, xx = xc - 1;
+    float v = 0.0f;
+    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+      const size_t o = (((size_t)b * CIN + ci) * a.H + yy) * a.W + xx;
+      const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
+      v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
+      if (a.x0_f32 && yy * a.W + xx >= p_lo && yy * a.W + xx < p_hi) a.x0_f32[o] = v;
+    }
+    slab[(ci * nrows_max + ry) * Wp + xc] = v;
+  }
   float wreg[8][9 * CIN];                                              // weights of this thread's 8 channels
-  if (pl < lanes)
-    for (int j = 0; j < 8; ++j)
-      for (int k = 0; k < 9 * CIN; ++k) wreg[j][k] = a.w[(size_t)(c8 * 8 + j) * CIN * 9 + k];
-  double ssum[8], ssq[8];
+  float bj[8];
+  if (pl < lanes) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { ssum[j] = 0.0; ssq[j] = 0.0; }
+    for (int j = 0; j < 8; ++j) {
+      bj[j] = a.bias[c8 * 8 + j];
+#pragma unroll
+      for (int k = 0; k < 9 * CIN; ++k) wreg[j][k] = a.w[(size_t)(c8 * 8 + j) * CIN * 9 + k];
+    }
+  }
+  __syncthreads();
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; ssq[j] = 0.0f; }
   if (pl < lanes)
     for (int r = p_lo + pl; r < p_hi; r += lanes) {
       const int y = r / a.W, x = r % a.W;
       float acc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = a.bias[c8 * 8 + j];
+      for (int j = 0; j < 8; ++j) acc[j] = bj[j];
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy) {
+          const float* row = slab + (ci * nrows_max + (y - y_lo + dy)) * Wp + x;     // columns x-1 .. x+1 of the image = x .. x+2 here
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
-            const int yy = y + dy - 1, xx = x + dx - 1;
-            if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
-            const size_t o = (((size_t)b * CIN + ci) * a.H + yy) * a.W + xx;
-            const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
-            const float v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
+            const float v = row[dx];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wreg[j][(ci * 3 + dy) * 3 + dx], acc[j]);
           }
-      if (a.x0_f32 && c8 == 0)
-        for (int ci = 0; ci < CIN; ++ci) {
-          const size_t o = (((size_t)b * CIN + ci) * a.H + y) * a.W + x;
-          const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
-          a.x0_f32[o] = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
         }
       const size_t o = ((size_t)b * HW + r) * a.Cout + c8 * 8;
       if (a.out_f32) {
@@ -1332,17 +1348,22 @@ __global__ __launch_bounds__(256) void k_first_conv(const FirstConvArgs a) {
         *(uint4*)(a.out_hi + o) = make_uint4(pack2_bf16(acc[0], acc[1]), pack2_bf16(acc[2], acc[3]),
                                              pack2_bf16(acc[4], acc[5]), pack2_bf16(acc[6], acc[7]));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ssum[j] += acc[j]; ssq[j] += (double)acc[j] * acc[j]; }
+      for (int j = 0; j < 8; ++j) { ssum[j] += acc[j]; ssq[j] = fmaf(acc[j], acc[j], ssq[j]); }
     }
   if (a.stats) {
-    if (pl < lanes)
+    if (pl < lanes) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        atomicAdd(&sred[(c8 * 8 + j) * 2], ssum[j]);
-        atomicAdd(&sred[(c8 * 8 + j) * 2 + 1], ssq[j]);
+        part[(pl * a.Cout + c8 * 8 + j) * 2] = ssum[j];
+        part[(pl * a.Cout + c8 * 8 + j) * 2 + 1] = ssq[j];
       }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) atomicAdd(a.stats + (size_t)b * a.Cout * 2 + i, sred[i]);
+    for (int i = threadIdx.x; i < 2 * a.Cout; i += 256) {
+      double t = 0.0;
+      for (int q = 0; q < lanes; ++q) t += (double)part[q * a.Cout * 2 + i];
+      atomicAdd(a.stats + (size_t)b * a.Cout * 2 + i, t);
+    }
   }
 }
 
@@ -1824,7 +1845,8 @@ extern "C" int ctdd_unet_first_conv(const void* args_, void* stream) {
   const int lanes = 256 / (a.Cout / 8);
   int gx = (a.H * a.W + 8 * lanes - 1) / (8 * lanes);     // ~8 pixels per thread
   if (gx < 1) gx = 1;
-  const size_t lds = (size_t)2 * a.Cout * sizeof(double);
+  const size_t lds = ((size_t)a.Cin * first_conv_rows(a.H * a.W, a.W, gx) * (a.W + 2) + (size_t)lanes * a.Cout * 2) * sizeof(float);
+  CTDD_REQUIRE(lds <= 64 * 1024, CTDD_ERANGE, "first conv: %zu bytes of LDS", lds);
   hipStream_t st = (hipStream_t)stream;
   switch (a.Cin) {
     case 1: hipLaunchKernelGGL(k_first_conv<1>, dim3(gx, a.B), dim3(256), lds, st, a); break;
