@@ -53,7 +53,7 @@ __device__ inline unsigned short bf16_rne(float f) {
 }
 __device__ inline float bf16_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-__global__ __launch_bounds__(256) void k_step_tables(const float* __restrict__ qt0, float eps, int nT,
+__global__ __launch_bounds__(256) void k_step_tables(const float* __restrict__ qt0, float eps, int nT, int crm,
                                                      unsigned char* __restrict__ out) {
   const int t = blockIdx.y;
   const float* q = qt0 + (size_t)t * S256 * S256;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_step_tables(const float* __restrict__ q
   for (int r = 0; r < 16; ++r) {
     const int s0 = 16 * kk + r;
     const float v = q[(size_t)s0 * S256 + s];
-    invq[(size_t)s * S256 + s0] = 1.0f / (v + eps);          // transposed write (x = s here)
+    invq[(size_t)s * S256 + s0] = crm ? 1.0f : 1.0f / (v + eps);   // transposed write (x = s here); CRM branch: plain p0t @ qt0
     const unsigned short hi = bf16_rne(v);
     const unsigned short lo = bf16_rne(v - bf16_to_f32(hi));
     const int g = r >> 3, j = r & 7;
@@ -327,7 +327,22 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
   // acc *= RT0[x_j][s] (forward rate R[s][x], own state pre-zeroed), read in accumulator order
   // straight from the L2-resident 256-KiB view (two adjacent 16-B pieces per row per instruction).
   const bool corrector = a.flags & CTDD_STEP_CORRECTOR;
-  const float invz = 1.0f / zv;
+  // CRM branch with logit_type reverse_prob (sampling.py:61-73, model_utils.py:30-60): the step tables carry invq = 1, so
+  // acc[s] = Z (p0t @ qt0)[s]; ratio[s] = exp(ll_all[s] - ll_xt) = (acc[s] + 1e-35 Z) / (acc[x] + 1e-35 Z) and the rate
+  // view is R[x][s] (the launcher passes R0 as the view): same epilogue with acc[x] + 1e-35 Z in the place of Z.
+  const bool crm = a.flags & CTDD_STEP_CRM;
+  float norm = zv, addn = 0.0f;
+  if (crm) {
+    float ox = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ox = (32 * m + 8 * (r >> 2) + 4 * g + (r & 3) == xj) ? acc[m][r] : ox;
+    ox += __shfl_xor(ox, 32, WAVE);                            // (the pair's other lane holds it, or 0)
+    addn = 1e-35f * zv;
+    norm = ox + addn;
+  }
+  const float invz = 1.0f / norm;
   const float scale = a.beta * invz;                            // true rate = scale * r
   const int64_t myrow = wrow0 + j;
   const bool live = myrow < a.R;
@@ -343,10 +358,11 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 f = fpre[4 * m + q];
-      float v0 = acc[m][4 * q + 0] * f.x, v1 = acc[m][4 * q + 1] * f.y, v2 = acc[m][4 * q + 2] * f.z, v3 = acc[m][4 * q + 3] * f.w;
-      if (corrector) {                                          // r_s += Z * R[x][s]
+      float v0 = (acc[m][4 * q + 0] + addn) * f.x, v1 = (acc[m][4 * q + 1] + addn) * f.y, v2 = (acc[m][4 * q + 2] + addn) * f.z,
+            v3 = (acc[m][4 * q + 3] + addn) * f.w;
+      if (corrector) {                                          // r_s += Z * R[x][s]  (Z: the normaliser in use)
         const float4 c = *(const float4*)(crow + 32 * m + 8 * q);
-        v0 = fmaf(zv, c.x, v0); v1 = fmaf(zv, c.y, v1); v2 = fmaf(zv, c.z, v2); v3 = fmaf(zv, c.w, v3);
+        v0 = fmaf(norm, c.x, v0); v1 = fmaf(norm, c.y, v1); v2 = fmaf(norm, c.z, v2); v3 = fmaf(norm, c.w, v3);
       }
       T += (v0 + v1) + (v2 + v3);
       rl4[(4 * m + q) * 64] = make_float4(v0, v1, v2, v3);
@@ -465,12 +481,22 @@ using namespace ctdd;
 
 extern "C" int64_t ctdd_s256_step_table_bytes(void) { return (int64_t)STEP_TABLE_BYTES; }
 
+static int s256_prepare(const float* qt0, const float* base_rate, float eps, int nT, int crm, void* out_step_tables, float* out_RT0,
+                        float* out_R0, void* stream);
 extern "C" int ctdd_s256_prepare(const float* qt0, const float* base_rate, float eps, int nT,
                                  void* out_step_tables, float* out_RT0, float* out_R0, void* stream) {
+  return s256_prepare(qt0, base_rate, eps, nT, 0, out_step_tables, out_RT0, out_R0, stream);
+}
+extern "C" int ctdd_s256_prepare_crm(const float* qt0, const float* base_rate, int nT, void* out_step_tables, float* out_RT0,
+                                     float* out_R0, void* stream) {
+  return s256_prepare(qt0, base_rate, 0.0f, nT, 1, out_step_tables, out_RT0, out_R0, stream);
+}
+static int s256_prepare(const float* qt0, const float* base_rate, float eps, int nT, int crm, void* out_step_tables, float* out_RT0,
+                        float* out_R0, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (out_step_tables) {
     CTDD_REQUIRE(qt0 && nT > 0 && nT <= 65535, CTDD_EINVAL, "bad qt0 / nT=%d", nT);
-    hipLaunchKernelGGL(k_step_tables, dim3(16, nT), dim3(256), 0, st, qt0, eps, nT, (unsigned char*)out_step_tables);
+    hipLaunchKernelGGL(k_step_tables, dim3(16, nT), dim3(256), 0, st, qt0, eps, nT, crm, (unsigned char*)out_step_tables);
     if (int rc = finish_launch("k_step_tables")) return rc;
   }
   if (out_RT0 || out_R0) {
@@ -490,7 +516,8 @@ extern "C" int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, con
   CTDD_REQUIRE(N > 0 && D > 0, CTDD_EINVAL, "N=%d D=%d must be positive", N, D);
   S256Args a{};
   a.logits = logits; a.x = x; a.x_base = x_base; a.tables = (const unsigned char*)step_tables;
-  a.RT0 = RT0; a.R0 = R0; a.beta = beta; a.h = h; a.flags = flags; a.seed = seed; a.offset = offset;
+  a.RT0 = (flags & CTDD_STEP_CRM) ? R0 : RT0;      // CRM branch: forward rate out of x, R[x][s]
+  a.R0 = R0; a.beta = beta; a.h = h; a.flags = flags; a.seed = seed; a.offset = offset;
   a.R = (int64_t)N * D; a.out_rates = out_rates; a.out_x = out_x; a.out_changed = out_changed;
   const int64_t grid = (a.R + TILE_ROWS - 1) / TILE_ROWS;
   CTDD_REQUIRE(grid < (1ll << 31), CTDD_ERANGE, "too many rows");

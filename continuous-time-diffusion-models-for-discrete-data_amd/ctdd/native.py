@@ -16,7 +16,7 @@ _LIB = None
 
 BRANCH_CTELBO, BRANCH_CRM = 0, 1
 LOGIT_TYPES = {"direct": 0, "reverse_prob": 1, "reverse_logscale": 2}
-STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW = 1, 2, 4
+STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM = 1, 2, 4, 8
 
 
 class CtddError(RuntimeError):
@@ -46,6 +46,7 @@ _SIGS = {
     "ctdd_philox_uniform": ([_U64, _U64, _I64, _I, _P, _P], _I),
     "ctdd_s256_step_table_bytes": ([], _I64),
     "ctdd_s256_prepare": ([_P, _P, _F, _I, _P, _P, _P, _P], _I),
+    "ctdd_s256_prepare_crm": ([_P, _P, _I, _P, _P, _P, _P], _I),
     "ctdd_tauleap_step_s256": ([_P, _P, _P, _P, _P, _P, _F, _F, _U32, _U64, _U64, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_crm_loss": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_ctelbo_scratch_bytes": ([_I, _I, _I], _I64),
@@ -287,7 +288,9 @@ class S256Tables:
     """Derived tables for the MFMA tau-leaping kernel: per-step blocks (resident for the whole
     time grid) + the two per-model base-rate views."""
 
-    def __init__(self, qt0, base_rate, eps):
+    def __init__(self, qt0, base_rate, eps, crm=False):
+        """crm: tables of the CRM branch with logit_type reverse_prob (unit left scaling; step calls carry STEP_CRM)."""
+        self.crm = bool(crm)
         nT, S, _ = qt0.shape
         if S != 256:
             raise CtddError("S256Tables needs S == 256")
@@ -296,8 +299,12 @@ class S256Tables:
         self.steps = torch.empty((nT, self.block), dtype=torch.uint8, device=dev)
         self.RT0 = torch.empty((S, S), dtype=f32, device=dev)
         self.R0 = torch.empty((S, S), dtype=f32, device=dev)
-        rc = load().ctdd_s256_prepare(_ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), float(eps), nT,
-                                      _ptr(self.steps), _ptr(self.RT0), _ptr(self.R0), _stream())
+        if self.crm:
+            rc = load().ctdd_s256_prepare_crm(_ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), nT,
+                                              _ptr(self.steps), _ptr(self.RT0), _ptr(self.R0), _stream())
+        else:
+            rc = load().ctdd_s256_prepare(_ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), float(eps), nT,
+                                          _ptr(self.steps), _ptr(self.RT0), _ptr(self.R0), _stream())
         _check(rc, "ctdd_s256_prepare")
 
     def step_ptr(self, i):
@@ -314,7 +321,7 @@ def tauleap_step_s256(logits, x, tables, i, beta, h, flags, seed, offset, x_base
         out = torch.empty((N, D), dtype=i32, device=x.device)
     rc = load().ctdd_tauleap_step_s256(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"),
                                        tables.step_ptr(i), _ptr(tables.RT0), _ptr(tables.R0), float(beta), float(h),
-                                       int(flags), seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
+                                       int(flags) | (STEP_CRM if tables.crm else 0), seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
                                        _ptr(changed, i32, "changed"), _stream())
     _check(rc, "ctdd_tauleap_step_s256")
     return (out, rates) if want_rates else out

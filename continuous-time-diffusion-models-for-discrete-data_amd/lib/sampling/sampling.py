@@ -98,10 +98,13 @@ class _GridSampler:
         return native.argmax(model(x.long(), t).float().contiguous())
 
     def _fast_tables(self, model, qt0):
-        """S = 256 CT-ELBO branch: derived tables for the MFMA kernel (csrc/steps_s256.hip)."""
-        if self.S == 256 and self.branch == native.BRANCH_CTELBO and qt0 is not None \
-                and getattr(self.cfg.sampler, "fast_s256", True):
+        """S = 256, CT-ELBO branch or CRM branch with reverse_prob logits: derived tables for the MFMA kernel (csrc/steps_s256.hip)."""
+        if self.S != 256 or qt0 is None or not getattr(self.cfg.sampler, "fast_s256", True):
+            return None
+        if self.branch == native.BRANCH_CTELBO:
             return native.S256Tables(qt0, model.process.base_rate, self.eps_ratio)
+        if self.logit_type == "reverse_prob":                    # CRM branch: the same contraction with a unit left scaling
+            return native.S256Tables(qt0, model.process.base_rate, 0.0, crm=True)
         return None
 
     def _leap(self, model, logits, x, q_i, fast, i, beta, h, flags, key, offset, x_base=None, changed=None):

@@ -46,6 +46,8 @@ extern "C" {
 #define CTDD_STEP_ORDINAL 1u     /* cfg.sampler.is_ordinal (sampling.py:135-138)                 */
 #define CTDD_STEP_CORRECTOR 2u   /* add rate[x][s] to R^ (corrector, sampling.py:182-198)        */
 #define CTDD_STEP_COUNT_RAW 4u   /* out_changed counts the UNCLIPPED move != 0 (sampling.py:505) */
+#define CTDD_STEP_CRM 8u         /* ctdd_tauleap_step_s256 only: CRM-branch rates with logit_type reverse_prob (sampling.py:61-73);
+                                  * the step tables must come from ctdd_s256_prepare_crm */
 
 int ctdd_abi_version(void);
 const char* ctdd_last_error(void);
@@ -152,6 +154,11 @@ int ctdd_initial_samples(const float* cdf, uint64_t seed, uint64_t offset, int N
 int64_t ctdd_s256_step_table_bytes(void);
 int ctdd_s256_prepare(const float* qt0, const float* base_rate, float eps, int nT,
                       void* out_step_tables, float* out_RT0, float* out_R0, void* stream);
+/* CRM branch, logit_type reverse_prob (sampling.py:61-73 with model_utils.py:40-47): ratio = exp(ll_all - ll_xt) with
+ * ll_all = log(softmax(logits) @ qt0 + 1e-35), rates = ratio * beta * R[x][s].  The same contraction with a unit left
+ * scaling: tables from ctdd_s256_prepare_crm, step call with CTDD_STEP_CRM in flags. */
+int ctdd_s256_prepare_crm(const float* qt0, const float* base_rate, int nT, void* out_step_tables, float* out_RT0,
+                          float* out_R0, void* stream);
 /* Same semantics as ctdd_tauleap_step(branch = CTELBO) for S = 256 (lib/sampling/sampling.py:
  * 119-160, 165-221, 459-508).  step_tables points at THIS step's block.  out_rates (N,D,256),
  * optional, receives the masked reverse rates (validation / unfused use); out_x may then be NULL. */

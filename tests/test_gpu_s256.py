@@ -129,3 +129,47 @@ def test_full_size_properties(env):
     # non-ordinal: a dimension with two or more jumps stays, so no more dimensions move than in the ordinal run with the same stream
     d = native.tauleap_step_s256(logits, x, tabs, 0, beta, 2e-3, 0, 7, 11)
     assert int((d != x).sum()) <= moved
+
+
+@pytest.mark.parametrize("t,scale,N,D", [(0.5, 1.0, 3, 100), (0.05, 4.0, 2, 131), (0.97, 2.0, 1, 784)])
+def test_crm_reverse_prob_rates_match_oracle(env, t, scale, N, D):
+    """CRM branch with logit_type reverse_prob on the same MFMA kernel (STEP_CRM, tables with a unit left scaling):
+    rates = exp(ll_all - ll_xt) * beta R[x][s] (sampling.py:61-73), rtol 1e-4 against the oracle."""
+    native, pr, op = env
+    logits, x = _case(N, D, 11, scale)
+    tt = torch.tensor([t])
+    qt0 = op.transition(tt).cuda()
+    tabs = native.S256Tables(qt0, pr.base_rate, 0.0, crm=True)
+    beta = float(pr.beta(tt)[0])
+    _, rates = native.tauleap_step_s256(logits.cuda().contiguous(), x.to(torch.int32).cuda(), tabs, 0, beta, 1e-3, 1, 1, 0,
+                                        want_rates=True)
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    ref = ops.zero_own_state(ops.reverse_rates_crm("reverse_prob", logits, x, q, r)[0], x)
+    np.testing.assert_allclose(rates.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-25)
+
+
+@pytest.mark.parametrize("flags", [1, 3])
+def test_crm_fused_step_matches_generic_and_replay(env, flags):
+    native, pr, op = env
+    N, D = 4, 300
+    logits, x = _case(N, D, 15, 2.0)
+    tt = torch.tensor([0.4])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = ops.reverse_rates_crm("reverse_prob", logits, x, q, r)[0]
+    if flags & 2:
+        rr = rr + ops.transpose_forward_rates(r, x)
+    h = float(1.0 / ops.zero_own_state(rr, x).sum(-1).median())
+    tabs = native.S256Tables(qt0, pr.base_rate, 0.0, crm=True)
+    dl, dx = logits.cuda().contiguous(), x.to(torch.int32).cuda()
+    changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 77, 3, changed=changed).cpu().long()
+    gen = native.tauleap_step(native.BRANCH_CRM, "reverse_prob", dl, dx, qt0[0], pr.base_rate, beta, 1e-9, h, flags, 77, 3).cpu().long()
+    assert (out != gen).float().mean().item() < 3e-3          # same Philox stream; only fp near-ties differ
+    ref, decided = oph.tauleap_draw_replay(rr.numpy(), x.numpy(), h, bool(flags & 1), 77, 3)
+    dec = torch.from_numpy(decided)
+    assert dec.float().mean() > 0.6
+    assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 3e-3
+    assert int(changed.item()) == int((out != x).sum())
+    assert (out != x).float().mean() > 0.05
