@@ -75,24 +75,49 @@ __global__ __launch_bounds__(256) void k_hollow_layernorm(const HollowLnArgs a) 
   const int b = (int)(row / a.T), j = (int)(row % a.T), E = a.E;
   const float* x = a.x + (size_t)b * a.x_bs + (size_t)j * E;
   const float* y = a.y ? a.y + (size_t)b * a.y_bs + (size_t)j * E : nullptr;
+  float* o = a.out ? a.out + (size_t)b * a.out_bs + (size_t)j * E : nullptr;
+  unsigned short* oh = a.out_hi ? a.out_hi + (size_t)b * a.out_hi_bs + (size_t)j * E : nullptr;
+  unsigned short* ol = (oh && a.out_lo) ? a.out_lo + (size_t)b * a.out_hi_bs + (size_t)j * E : nullptr;
+  auto emit = [&](int e, float v) {
+    if (a.film) v = a.film[(size_t)b * a.film_stride + e] * v + a.film[(size_t)b * a.film_stride + E + e];
+    if (o) o[e] = v;
+    if (oh) {
+      const unsigned short hv = hk_bf16(v);
+      oh[e] = hv;
+      if (ol) ol[e] = hk_lo(v, hv);
+    }
+  };
+  if (E <= 512) {                                   // the row lives in registers: one pass over memory
+    float xv[8];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = lane + 64 * k;
+      xv[k] = e < E ? x[e] + (y ? y[e] : 0.0f) : 0.0f;
+      s += xv[k];
+    }
+    const float mean = wave_sum(s) / (float)E;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d = lane + 64 * k < E ? xv[k] - mean : 0.0f;
+      q = fmaf(d, d, q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + a.eps);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = lane + 64 * k;
+      if (e < E) emit(e, (xv[k] - mean) * rstd * a.gamma[e] + a.beta[e]);
+    }
+    return;
+  }
   float s = 0.0f;
   for (int e = lane; e < E; e += 64) s += x[e] + (y ? y[e] : 0.0f);
   const float mean = wave_sum(s) / (float)E;
   float q = 0.0f;
   for (int e = lane; e < E; e += 64) { const float d = x[e] + (y ? y[e] : 0.0f) - mean; q = fmaf(d, d, q); }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + a.eps);
-  float* o = a.out ? a.out + (size_t)b * a.out_bs + (size_t)j * E : nullptr;
-  unsigned short* oh = a.out_hi ? a.out_hi + (size_t)b * a.out_hi_bs + (size_t)j * E : nullptr;
-  for (int e = lane; e < E; e += 64) {
-    float v = (x[e] + (y ? y[e] : 0.0f) - mean) * rstd * a.gamma[e] + a.beta[e];
-    if (a.film) v = a.film[(size_t)b * a.film_stride + e] * v + a.film[(size_t)b * a.film_stride + E + e];
-    if (o) o[e] = v;
-    if (oh) {
-      const unsigned short hv = hk_bf16(v);
-      oh[e] = hv;
-      if (a.out_lo) a.out_lo[(size_t)b * a.out_hi_bs + (size_t)j * E + e] = hk_lo(v, hv);
-    }
-  }
+  for (int e = lane; e < E; e += 64) emit(e, (x[e] + (y ? y[e] : 0.0f) - mean) * rstd * a.gamma[e] + a.beta[e]);
 }
 
 // out[b][j][:] = p[b][j][:] + q[b][j][:], strided batches
