@@ -230,13 +230,7 @@ __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const C
         rres[step] = (lane_ok && row < 32 && p < M) ? *(const uint4*)(p_res_bf16 + (size_t)p * aN + nc) : make_uint4(0, 0, 0, 0);
       }
     }
-    // ---- phase 1: column-per-lane accumulators -> row-major fp32 image
-#pragma unroll
-    for (int t = 0; t < BNT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xt[((r & 3) + 8 * (r >> 2) + 4 * g) * LD + t * 32 + li] = acc[mt][t][r];
-    ESTAMP(e1)
-    // ---- phase 2: one lane per (row, 8-column piece)
+    // per-sample (time) bias of the one or two samples of this slice: requested here, used after the LDS round trip
     const int b_first = (int)(base / HW);
     const int64_t next_sample = (int64_t)(b_first + 1) * HW;   // a 32-row slice spans at most two samples (HW >= 32)
     float tb0[8], tb1[8];
@@ -245,13 +239,36 @@ __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const C
       tb0[j] = (p_tbias && lane_ok) ? p_tbias[(size_t)b_first * a_tbs + nc + j] : 0.0f;
       tb1[j] = (p_tbias && lane_ok && b_first + 1 < aB) ? p_tbias[(size_t)(b_first + 1) * a_tbs + nc + j] : 0.0f;
     }
+    // ---- phase 1: column-per-lane accumulators -> row-major fp32 image
+#pragma unroll
+    for (int t = 0; t < BNT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xt[((r & 3) + 8 * (r >> 2) + 4 * g) * LD + t * 32 + li] = acc[mt][t][r];
+    ESTAMP(e1)
+    // ---- phase 2: one lane per (row, 8-column piece).  All the LDS reads of the slice are issued first, unconditionally
+    // (row clamped), so that their latencies overlap instead of one read -> wait -> use chain per step
+    // Statistics of a slice that lies inside ONE sample (all of them at 28x28, none at 7x7; wave-uniform): the lane sums its
+    // own rows' final values in registers, the RS lanes of a column piece meet through 2 RS rows of the (by then consumed)
+    // image, and the column pass adds RS partial sums instead of walking 32 rows.
+    const int nrows_s = (int)(M - base < 32 ? M - base : 32);
+    const bool one_sample = ts.lds && next_sample - base >= nrows_s && 2 * RS <= 32;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cs[j] = 0.0f; cq[j] = 0.0f; }
+    float4 xr0[STEPS], xr1[STEPS];
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+      const int rowc = min(step * RS + rsub, 31);
+      xr0[step] = *(const float4*)(xt + rowc * LD + cc * 8);
+      xr1[step] = *(const float4*)(xt + rowc * LD + cc * 8 + 4);
+    }
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
       const int row = step * RS + rsub;
       const int64_t p = base + row;
       if (lane_ok && row < 32 && p < M) {
         const bool second = p >= next_sample;
-        const float4 x0 = *(const float4*)(xt + row * LD + cc * 8), x1 = *(const float4*)(xt + row * LD + cc * 8 + 4);
+        const float4 x0 = xr0[step], x1 = xr1[step];
         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bv[j] + (second ? tb1[j] : tb0[j]);
@@ -296,11 +313,20 @@ __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const C
             *(uint4*)(p_out_lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
           }
         }
-        if (ts.lds) {                                      // final values back into the image for the column pass
+        if (one_sample) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] = fmaf(v[j], v[j], cq[j]); }
+        } else if (ts.lds) {                               // final values back into the image for the column pass
           *(float4*)(xt + row * LD + cc * 8) = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)(xt + row * LD + cc * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
       }
+    }
+    if (one_sample && lane_ok) {                           // (rsub < RS; every image read of this slice was issued above)
+      *(float4*)(xt + rsub * LD + cc * 8) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      *(float4*)(xt + rsub * LD + cc * 8 + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+      *(float4*)(xt + (RS + rsub) * LD + cc * 8) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+      *(float4*)(xt + (RS + rsub) * LD + cc * 8 + 4) = make_float4(cq[4], cq[5], cq[6], cq[7]);
     }
     ESTAMP(e2)
     // ---- phase 3: GroupNorm statistics, one lane per column down the slice's rows (fp64), so that the
@@ -309,6 +335,23 @@ __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const C
     if (ts.lds && !(CTDD_EPI_DBG & 1)) {
       const int nrows = (int)(M - base < 32 ? M - base : 32);
       const int split = (int)(next_sample - base < nrows ? next_sample - base : nrows);   // rows [0, split) belong to b_first
+      if (one_sample) {
+#pragma unroll
+        for (int c0 = 0; c0 < BN; c0 += 64) {
+          const int c = c0 + lane;
+          if (c < BN && n0 + c < aN) {
+            float sv[RS], qv[RS];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) { sv[r] = xt[r * LD + c]; qv[r] = xt[(RS + r) * LD + c]; }
+            double s0 = 0.0, q0 = 0.0;
+#pragma unroll
+            for (int r = 0; r < RS; ++r) { s0 += (double)sv[r]; q0 += (double)qv[r]; }
+            double* st = ts.lds + ((size_t)(b_first - ts.b0) * ts.BN + c) * 2;
+            atomicAdd(st, s0);
+            atomicAdd(st + 1, q0);
+          }
+        }
+      } else
 #pragma unroll
       for (int c0 = 0; c0 < BN; c0 += 64) {
         const int c = c0 + lane;
