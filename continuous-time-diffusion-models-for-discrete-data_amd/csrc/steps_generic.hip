@@ -35,25 +35,90 @@ struct StepArgs {
   int32_t* out_changed;
 };
 
+// ---- reductions / scans over the G lanes of a row on DPP (data-parallel primitives: one VALU op per stage) instead of
+// ds_bpermute shuffles (an LDS-crossbar round trip per stage: six dependent ones per 64-lane reduction, ~10 reductions and
+// a 28-stage scan per row made the shuffles, not memory, the bound of every mode).  G is uniform over the launch, so the
+// stage tests are scalar branches.  Stages inside a 16-lane row: quad_perm xor 1 / xor 2, row_half_mirror, row_mirror (the
+// operations are commutative, so a mirror does what an xor would); across rows: v_readlane of one lane per row.
+template <int CTRL>
+__device__ inline int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ inline float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+__device__ inline float rdlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
 __device__ inline float grp_sum(float v, int G) {
-  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  if (G >= 2) v += dpp_f<DPP_XOR1>(v);
+  if (G >= 4) v += dpp_f<DPP_XOR2>(v);
+  if (G >= 8) v += dpp_f<DPP_HALF_MIRROR>(v);
+  if (G >= 16) v += dpp_f<DPP_MIRROR>(v);
+  if (G >= 32) {
+    const float r0 = rdlane_f(v, 0), r1 = rdlane_f(v, 16), r2 = rdlane_f(v, 32), r3 = rdlane_f(v, 48);
+    v = G == 64 ? (r0 + r1) + (r2 + r3) : ((threadIdx.x & 32) ? r2 + r3 : r0 + r1);
+  }
   return v;
 }
 __device__ inline int grp_sum_i(int v, int G) {
-  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  if (G >= 2) v += dpp_i<DPP_XOR1>(v);
+  if (G >= 4) v += dpp_i<DPP_XOR2>(v);
+  if (G >= 8) v += dpp_i<DPP_HALF_MIRROR>(v);
+  if (G >= 16) v += dpp_i<DPP_MIRROR>(v);
+  if (G >= 32) {
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16), r2 = __builtin_amdgcn_readlane(v, 32),
+              r3 = __builtin_amdgcn_readlane(v, 48);
+    v = G == 64 ? (r0 + r1) + (r2 + r3) : ((threadIdx.x & 32) ? r2 + r3 : r0 + r1);
+  }
   return v;
 }
 __device__ inline float grp_max(float v, int G) {
-  for (int m = G >> 1; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, WAVE));
+  if (G >= 2) v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+  if (G >= 4) v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+  if (G >= 8) v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+  if (G >= 16) v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+  if (G >= 32) {
+    const float r0 = rdlane_f(v, 0), r1 = rdlane_f(v, 16), r2 = rdlane_f(v, 32), r3 = rdlane_f(v, 48);
+    v = G == 64 ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : ((threadIdx.x & 32) ? fmaxf(r2, r3) : fmaxf(r0, r1));
+  }
   return v;
 }
 // (value, index) arg-max with first-index tie-break (torch.argmax)
+__device__ inline void argmax_pick(float& v, int& i, float ov, int oi) {
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
 __device__ inline void grp_argmax(float& v, int& i, int G) {
-  for (int m = G >> 1; m >= 1; m >>= 1) {
-    const float ov = __shfl_xor(v, m, WAVE);
-    const int oi = __shfl_xor(i, m, WAVE);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  if (G >= 2) { const float ov = dpp_f<DPP_XOR1>(v); const int oi = dpp_i<DPP_XOR1>(i); argmax_pick(v, i, ov, oi); }
+  if (G >= 4) { const float ov = dpp_f<DPP_XOR2>(v); const int oi = dpp_i<DPP_XOR2>(i); argmax_pick(v, i, ov, oi); }
+  if (G >= 8) { const float ov = dpp_f<DPP_HALF_MIRROR>(v); const int oi = dpp_i<DPP_HALF_MIRROR>(i); argmax_pick(v, i, ov, oi); }
+  if (G >= 16) { const float ov = dpp_f<DPP_MIRROR>(v); const int oi = dpp_i<DPP_MIRROR>(i); argmax_pick(v, i, ov, oi); }
+  if (G >= 32) {
+    const int hi = (G == 64) ? 0 : (int)(threadIdx.x & 32);          // first row of this lane's group
+    float bv = rdlane_f(v, 0), b1 = rdlane_f(v, 16), b2 = rdlane_f(v, 32), b3 = rdlane_f(v, 48);
+    int bi = __builtin_amdgcn_readlane(i, 0), i1 = __builtin_amdgcn_readlane(i, 16), i2 = __builtin_amdgcn_readlane(i, 32),
+        i3 = __builtin_amdgcn_readlane(i, 48);
+    if (G == 64) {
+      argmax_pick(bv, bi, b1, i1); argmax_pick(bv, bi, b2, i2); argmax_pick(bv, bi, b3, i3);
+      v = bv; i = bi;
+    } else {
+      argmax_pick(bv, bi, b1, i1);
+      argmax_pick(b2, i2, b3, i3);
+      v = hi ? b2 : bv; i = hi ? i2 : bi;
+    }
   }
+}
+// inclusive prefix sum over the G lanes of a row group, lane order (li = lane within the group)
+__device__ inline float grp_scan(float v, int G, int li) {
+  const int pos = li & 15;                                             // place inside the 16-lane DPP row
+  if (G >= 2) { const float t = dpp_f<0x111>(v); v += pos >= 1 ? t : 0.0f; }    // row_shr:1 (lanes without a source read 0)
+  if (G >= 4) { const float t = dpp_f<0x112>(v); v += pos >= 2 ? t : 0.0f; }
+  if (G >= 8) { const float t = dpp_f<0x114>(v); v += pos >= 4 ? t : 0.0f; }
+  if (G >= 16) { const float t = dpp_f<0x118>(v); v += pos >= 8 ? t : 0.0f; }
+  if (G >= 32) {
+    const float t0 = rdlane_f(v, 15), t1 = rdlane_f(v, 31), t2 = rdlane_f(v, 47);
+    const int r = (threadIdx.x >> 4) & 3;
+    if (G == 64) v += r == 0 ? 0.0f : r == 1 ? t0 : r == 2 ? t0 + t1 : (t0 + t1) + t2;
+    else v += r == 1 ? t0 : r == 3 ? t2 : 0.0f;
+  }
+  return v;
 }
 
 template <int EPT>
@@ -119,7 +184,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
         for (int j = 0; j < G; ++j) {
           const int s0 = j + k0 * G;
           if (s0 >= S) break;
-          const float ws = __shfl(w[k0], gbase + j, WAVE);
+          const float ws = G == 1 ? w[k0] : __shfl(w[k0], gbase + j, WAVE);
           const float* qrow = qt0 + (size_t)s0 * S;
 #pragma unroll
           for (int k = 0; k < EPT; ++k) {
@@ -150,7 +215,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
           for (int j = 0; j < G; ++j) {
             const int s0 = j + k0 * G;
             if (s0 >= S) break;
-            const float ps = __shfl(e[k0] / z, gbase + j, WAVE);
+            const float ps = G == 1 ? e[k0] / z : __shfl(e[k0] / z, gbase + j, WAVE);
             const float* qrow = qt0 + (size_t)s0 * S;
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
@@ -171,7 +236,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
             for (int j = 0; j < G; ++j) {
               const int s0 = j + k0 * G;
               if (s0 >= S) break;
-              const float lp = __shfl(l[k0] - m - logz, gbase + j, WAVE);
+              const float lp = G == 1 ? l[k0] - m - logz : __shfl(l[k0] - m - logz, gbase + j, WAVE);
               const float* qrow = qt0 + (size_t)s0 * S;
 #pragma unroll
               for (int k = 0; k < EPT; ++k) {
@@ -193,7 +258,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
       float sel = 0.0f;
 #pragma unroll
       for (int k = 0; k < EPT; ++k) sel = (k == xv / G) ? ll[k] : sel;
-      const float ll_xt = __shfl(sel, gbase + (xv & (G - 1)), WAVE);
+      const float ll_xt = G == 1 ? sel : __shfl(sel, gbase + (xv & (G - 1)), WAVE);
       if (a.mode == MODE_LOGPROB) {
         if (live) {
 #pragma unroll
@@ -324,13 +389,8 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
       float c[EPT], carry = 0.0f;
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
-        float v = rr[k];
-        for (int d = 1; d < G; d <<= 1) {
-          const float t = __shfl_up(v, d, WAVE);
-          if (li >= d) v += t;
-        }
-        c[k] = v + carry;
-        carry = __shfl(c[k], gbase + G - 1, WAVE);
+        c[k] = grp_scan(rr[k], G, li) + carry;
+        carry = G == 64 ? rdlane_f(c[k], 63) : G == 1 ? c[k] : __shfl(c[k], gbase + G - 1, WAVE);
       }
       for (int j = 0; j < K; ++j) {
         const float target = rng.next() * T;
@@ -351,8 +411,8 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     for (int k = 0; k < EPT; ++k) {
       const int s = li + k * G;
       float r1, r2, r3;
-      if (G >= 4) {
-        r1 = __shfl(rr[k], lane + 1, WAVE); r2 = __shfl(rr[k], lane + 2, WAVE); r3 = __shfl(rr[k], lane + 3, WAVE);
+      if (G >= 4) {                  // the owner of 4b sits at quad position 0: its neighbours are the quad's other three lanes
+        r1 = dpp_f<0x55>(rr[k]); r2 = dpp_f<0xAA>(rr[k]); r3 = dpp_f<0xFF>(rr[k]);
       } else if (G == 2) {           // s, s+1 in lanes li, li+1 of slot k; s+2, s+3 in slot k+1
         r1 = __shfl(rr[k], lane + 1, WAVE);
         const float nx = k + 1 < EPT ? rr[k + 1] : 0.0f;
@@ -388,6 +448,7 @@ static int launch_rows(const StepArgs& a0, void* stream) {
   StepArgs a = a0;
   int G = 1;
   while (G < a.S && G < 64) G <<= 1;
+  if (a.S <= 4) G = 1;          // maze (S = 3), synthetic (S = 2): a row per LANE -- 64 rows share a wave's instruction stream
   a.G = G;
   const int ept_need = (a.S + G - 1) / G;
   const int64_t R = (int64_t)a.N * a.D;
