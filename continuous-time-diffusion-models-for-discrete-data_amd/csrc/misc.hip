@@ -99,12 +99,81 @@ extern "C" int ctdd_tauleap_apply(const int32_t* x, const int32_t* x_base, const
   return finish_launch("k_tauleap_apply");
 }
 
+namespace ctdd {
+// S = 256 (MNIST / CIFAR logits): a row is ONE 16-byte load per lane; a wave keeps eight rows in flight, reduces each on DPP
+// (no LDS, no shuffles) and stores the eight indices from eight lanes.  HBM-bound: 1 KiB read per row.
+template <int CTRL>
+__device__ inline int am_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ inline float am_dpp_f(float v) { return __builtin_bit_cast(float, am_dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+__device__ inline void am_pick(float& v, int& i, float ov, int oi) {
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(256) void k_argmax_s256(const float* __restrict__ logits, int64_t R, int32_t* __restrict__ out) {
+  constexpr int RPW = 8;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t base = wave_g * RPW; base < R; base += nwaves * RPW) {
+    float4 v[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int64_t row = base + r < R ? base + r : R - 1;
+      v[r] = *(const float4*)(logits + (size_t)row * 256 + lane * 4);
+    }
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      float b = v[r].x;
+      int bi = lane * 4;
+      if (v[r].y > b) { b = v[r].y; bi = lane * 4 + 1; }
+      if (v[r].z > b) { b = v[r].z; bi = lane * 4 + 2; }
+      if (v[r].w > b) { b = v[r].w; bi = lane * 4 + 3; }
+      am_pick(b, bi, am_dpp_f<0xB1>(b), am_dpp_i<0xB1>(bi));          // xor 1
+      am_pick(b, bi, am_dpp_f<0x4E>(b), am_dpp_i<0x4E>(bi));          // xor 2
+      am_pick(b, bi, am_dpp_f<0x141>(b), am_dpp_i<0x141>(bi));        // row_half_mirror
+      am_pick(b, bi, am_dpp_f<0x140>(b), am_dpp_i<0x140>(bi));        // row_mirror
+      float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 0));
+      int i0 = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        am_pick(b0, i0, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 16 * q)),
+                __builtin_amdgcn_readlane(bi, 16 * q));
+      mine = lane == r ? i0 : mine;
+    }
+    if (lane < RPW && base + lane < R) out[base + lane] = mine;
+  }
+}
+// S <= 8 (maze, synthetic): a row per lane
+__global__ __launch_bounds__(256) void k_argmax_small(const float* __restrict__ logits, int64_t R, int S, int32_t* __restrict__ out) {
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < R; row += (int64_t)gridDim.x * 256) {
+    const float* l = logits + (size_t)row * S;
+    float best = l[0];
+    int bi = 0;
+    for (int s_ = 1; s_ < S; ++s_) {
+      const float v = l[s_];
+      if (v > best) { best = v; bi = s_; }
+    }
+    out[row] = bi;
+  }
+}
+}  // namespace ctdd
+
 extern "C" int ctdd_argmax(const float* logits, int N, int D, int S, int32_t* out_x, void* stream) {
   CTDD_REQUIRE(logits && out_x, CTDD_EINVAL, "null logits/out");
   CTDD_REQUIRE(N > 0 && D > 0 && S >= 1, CTDD_EINVAL, "bad sizes N=%d D=%d S=%d", N, D, S);
+  const int64_t R = (int64_t)N * D;
+  if (S == 256) {
+    const int64_t want = (R + 31) / 32;                     // eight rows per wave and iteration
+    hipLaunchKernelGGL(k_argmax_s256, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, logits, R, out_x);
+    return finish_launch("k_argmax_s256");
+  }
+  if (S <= 8) {
+    const int64_t want = (R + 255) / 256;
+    hipLaunchKernelGGL(k_argmax_small, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, (hipStream_t)stream, logits, R, S, out_x);
+    return finish_launch("k_argmax_small");
+  }
   int G = 1;
   while (G < S && G < 64) G <<= 1;
-  const int64_t R = (int64_t)N * D;
   const int rows_per_wg = 4 * (64 / G);
   hipLaunchKernelGGL(k_argmax, dim3((unsigned)((R + rows_per_wg - 1) / rows_per_wg)), dim3(256), 0,
                      (hipStream_t)stream, logits, R, S, G, out_x);

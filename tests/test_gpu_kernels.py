@@ -375,6 +375,10 @@ def test_argmax_and_initial(nat):
     logits[0, 0, 7] = logits[0, 0, 200] = 9.0      # tie -> first index
     out = nat.argmax(dev(logits)).cpu().long()
     assert torch.equal(out, torch.argmax(logits, -1)) and out[0, 0] == 7
+    # every kernel variant (S = 256 vector path with a ragged row count, lane-per-row for S <= 8, generic), ties included
+    for S_, N_, D_ in ((256, 3, 171), (2, 5, 33), (3, 7, 225), (8, 2, 19), (40, 3, 17), (300, 2, 9)):
+        lg = torch.randn(N_, D_, S_, generator=g).round(decimals=1)       # one decimal: plenty of ties
+        assert torch.equal(nat.argmax(dev(lg)).cpu().long(), torch.argmax(lg, -1)), S_
     S, N, D = 256, 64, 784
     pmf = ops.gaussian_initial_pmf(S, 512.0)
     cdf = torch.from_numpy(np.cumsum(pmf)).float()
