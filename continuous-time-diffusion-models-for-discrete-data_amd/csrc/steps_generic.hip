@@ -121,24 +121,49 @@ __device__ inline float grp_scan(float v, int G, int li) {
   return v;
 }
 
+constexpr int ROWS_PER_WAVE = 4;
 template <int EPT>
 __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int G = a.G, S = a.S;
   const int li = lane & (G - 1), gi = lane / G, gbase = lane - li;
   const int64_t R = (int64_t)a.N * a.D;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * (WAVE / G) + gi;
+  // A wave walks ROWS_PER_WAVE consecutive row groups; the state and the logits of the NEXT group are requested before the
+  // current one is worked on (one row per wave and kernel lifetime left every load latency of the x -> table -> logits
+  // chain exposed: 7 us per row at S = 256).
+  const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * ROWS_PER_WAVE * (WAVE / G) + gi;
+  int nx_x = 0, nx_xb = 0;
+  float nx_l[EPT];
+  auto prefetch = [&](int64_t r) {
+    const int64_t rc = r < R ? r : R - 1;
+    nx_x = a.x[rc];
+    nx_xb = a.x_base ? a.x_base[rc] : 0;
+    const float* lr = a.logits + (size_t)rc * S;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int s = li + k * G;
+      nx_l[k] = s < S ? lr[s] : 0.0f;
+    }
+  };
+  prefetch(first);
+  for (int it = 0; it < ROWS_PER_WAVE; ++it) {
+  const int64_t row = first + (int64_t)it * (WAVE / G);
+  if (row - gi >= R) break;                                   // (uniform over the wave: the whole group is past the end)
   const bool live = row < R;
   const int64_t rowc = live ? row : R - 1;
+  const int cur_x = nx_x, cur_xb = nx_xb;
+  float raw[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) raw[k] = nx_l[k];
+  if (it + 1 < ROWS_PER_WAVE) prefetch(row + (WAVE / G));
   const int n = (int)(rowc / a.D);
   const int tbl = a.tidx ? a.tidx[n] : 0;
   const float* qt0 = a.qt0 ? a.qt0 + (size_t)tbl * S * S : nullptr;
   const float* rate = a.rate ? a.rate + (size_t)tbl * S * S : nullptr;
   // xcur = state the move is added to; xv = state the rates are evaluated at and measured from
   // (x' in stage 2 of the midpoint sampler, sampling.py:459-503; otherwise the same state)
-  const int xcur = min(max(a.x[rowc], 0), S - 1);
-  const int xv = a.x_base ? min(max(a.x_base[rowc], 0), S - 1) : xcur;
-  const float* lrow = a.logits + (size_t)rowc * S;
+  const int xcur = min(max(cur_x, 0), S - 1);
+  const int xv = a.x_base ? min(max(cur_xb, 0), S - 1) : xcur;
 
   float rr[EPT];     // reverse rates (own state NOT zeroed)
   float ratio[EPT];
@@ -147,7 +172,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int s = li + k * G;
-      rr[k] = s < S ? lrow[s] : 0.0f;
+      rr[k] = s < S ? raw[k] : 0.0f;
       ratio[k] = 0.0f;
     }
   } else {
@@ -157,7 +182,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int s = li + k * G;
-      l[k] = s < S ? lrow[s] : -INFINITY;
+      l[k] = s < S ? raw[k] : -INFINITY;
       m = fmaxf(m, l[k]);
     }
     m = grp_max(m, G);
@@ -268,7 +293,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
           }
           if (li == 0) a.out_b[row] = ll_xt;
         }
-        return;
+        continue;
       }
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
@@ -291,7 +316,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
         }
       }
     }
-    return;
+    continue;
   }
 
   // ---- mask the own state (sampling.py:127-128); corrector adds the x -> s forward rate first
@@ -310,7 +335,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     acc = grp_sum(acc, G);
     const int change = (int)rintf(a.h * acc);   // a.h carries float(0.5*h)
     if (live && li == 0) a.out_x[row] = min(max(xv + change, 0), S - 1);
-    return;
+    continue;
   }
 
   if (a.mode == MODE_LBJF) {
@@ -370,7 +395,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
       a.out_x[row] = bi;
       if (a.out_changed && bi != xv) atomicAdd(a.out_changed, 1);
     }
-    return;
+    continue;
   }
 
   // ---- MODE_TAULEAP / MODE_DRAW_ONLY: K ~ Poisson(h * sum rr), K destinations ~ Categorical(rr)
@@ -442,6 +467,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     const bool moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
     if (a.out_changed && moved) atomicAdd(a.out_changed, 1);
   }
+  }  // rows of this wave
 }
 
 static int launch_rows(const StepArgs& a0, void* stream) {
@@ -452,7 +478,7 @@ static int launch_rows(const StepArgs& a0, void* stream) {
   a.G = G;
   const int ept_need = (a.S + G - 1) / G;
   const int64_t R = (int64_t)a.N * a.D;
-  const int rows_per_wg = 4 * (64 / G);
+  const int rows_per_wg = 4 * ROWS_PER_WAVE * (64 / G);
   const int64_t grid = (R + rows_per_wg - 1) / rows_per_wg;
   CTDD_REQUIRE(grid > 0 && grid < (1ll << 31), CTDD_ERANGE, "rows out of range: %lld", (long long)R);
   hipStream_t st = (hipStream_t)stream;
