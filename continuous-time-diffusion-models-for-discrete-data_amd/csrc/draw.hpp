@@ -57,6 +57,16 @@ struct PhiloxStream {
 // Poisson(lam), lam > 12: PTRS (W. Hoermann, "The transformed rejection method for generating Poisson random
 // variables", 1993; the algorithm numpy and ATen use for large rates).  Two uniforms per trial, ~1.1-1.3 trials.
 // The acceptance test runs in fp64 (k log(lam) - lgamma(k+1) cancels ~1e7-sized terms at lam ~ 1e6).
+// log(k!) for an integral k >= 0 in fp64 without the library lgamma (whose register footprint -- ~170 VGPRs -- set the
+// occupancy of every kernel that can reach the heavy-rate draw): a 16-entry table, Stirling's series above it
+// (x = k + 1 >= 17: the first omitted term, 1/(1680 x^7), is below 3e-12).
+__device__ const double CTDD_LOG_FACTORIAL[16] = {0.0, 0.0, 0.693147180559945, 1.7917594692280554, 3.178053830347945, 4.787491742782047, 6.579251212010102, 8.525161361065415, 10.604602902745249, 12.801827480081467, 15.104412573075514, 17.502307845873887, 19.987214495661885, 22.55216385312342, 25.191221182738683, 27.89927138384089};
+__device__ inline double log_factorial(double kf) {
+  if (kf < 16.0) return CTDD_LOG_FACTORIAL[(int)kf];
+  const double x = kf + 1.0, xi = 1.0 / x, xi2 = xi * xi;
+  return (x - 0.5) * log(x) - x + 0.91893853320467274178 + xi * (1.0 / 12.0 - xi2 * (1.0 / 360.0 - xi2 * (1.0 / 1260.0)));
+}
+
 __device__ inline int poisson_ptrs(float lamf, PhiloxStream& rs) {
   const double lam = (double)lamf, slam = sqrt(lam), loglam = log(lam);
   const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
@@ -67,7 +77,7 @@ __device__ inline int poisson_ptrs(float lamf, PhiloxStream& rs) {
     const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
     if (us >= 0.07 && V <= vr) return (int)fmin(kf, 1.0e9);
     if (kf < 0.0 || (us < 0.013 && V > us)) continue;
-    if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) return (int)fmin(kf, 1.0e9);
+    if (log(V * invalpha / (a / (us * us) + b)) <= -lam + kf * loglam - log_factorial(kf)) return (int)fmin(kf, 1.0e9);
   }
   return (int)fmin(rint(lam), 1.0e9);                     // (32 rejections in a row: p < 1e-20)
 }
