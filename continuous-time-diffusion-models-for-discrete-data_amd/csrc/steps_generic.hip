@@ -29,6 +29,7 @@ struct StepArgs {
   uint64_t seed, offset;
   int N, D, S, G;
   int branch, logit_type, mode;
+  int pre_rates;         // `logits` holds the masked reverse rates already (from the S = 256 matrix-core kernel): any tail mode
   float* out_a;          // rates | ll_all | probs
   float* out_b;          // ratio | ll_xt
   int32_t* out_x;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   float rr[EPT];     // reverse rates (own state NOT zeroed)
   float ratio[EPT];
 
-  if (a.mode == MODE_DRAW_ONLY) {
+  if (a.mode == MODE_DRAW_ONLY || a.pre_rates) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int s = li + k * G;
@@ -599,6 +600,30 @@ extern "C" int ctdd_midpoint_predict(int branch, int logit_type, const float* lo
   a.logits = logits; a.x = x; a.qt0 = qt0; a.rate = base_rate; a.beta = beta; a.eps = eps;
   a.h = (float)(0.5 * (double)h);   // 0.5*h evaluated in double, then cast (sampling.py:437-439)
   a.N = N; a.D = D; a.S = S; a.branch = branch; a.logit_type = logit_type; a.mode = MODE_MIDPOINT;
+  a.out_x = out_x;
+  return launch_rows(a, stream);
+}
+
+/* LBJF / midpoint tails on reverse rates that are already computed and masked (rates (N,D,S): the out_rates of
+ * ctdd_tauleap_step_s256) -- the S = 256 samplers get their S x S contraction from the matrix-core kernel this way. */
+extern "C" int ctdd_lbjf_from_rates(const float* rates, const int32_t* x, float h, const float* E, uint64_t seed, uint64_t offset,
+                                    int N, int D, int S, int32_t* out_x, float* out_probs, int32_t* out_changed, void* stream) {
+  if (int rc = check_common(rates, x, N, D, S)) return rc;
+  CTDD_REQUIRE(out_x, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = rates; a.x = x; a.h = h; a.E = E; a.seed = seed; a.offset = offset; a.N = N; a.D = D; a.S = S;
+  a.mode = MODE_LBJF; a.pre_rates = 1;
+  a.out_x = out_x; a.out_a = out_probs; a.out_changed = out_changed;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_midpoint_from_rates(const float* rates, const int32_t* x, float h, int N, int D, int S, int32_t* out_x,
+                                        void* stream) {
+  if (int rc = check_common(rates, x, N, D, S)) return rc;
+  CTDD_REQUIRE(out_x, CTDD_EINVAL, "null output");
+  StepArgs a{};
+  a.logits = rates; a.x = x; a.h = (float)(0.5 * (double)h); a.N = N; a.D = D; a.S = S;
+  a.mode = MODE_MIDPOINT; a.pre_rates = 1;
   a.out_x = out_x;
   return launch_rows(a, stream);
 }

@@ -41,6 +41,8 @@ _SIGS = {
     "ctdd_tauleap_step": ([_I, _I, _P, _P, _P, _P, _P, _F, _F, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
     "ctdd_lbjf_step": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _U32, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_midpoint_predict": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _P, _P], _I),
+    "ctdd_lbjf_from_rates": ([_P, _P, _F, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_midpoint_from_rates": ([_P, _P, _F, _I, _I, _I, _P, _P], _I),
     "ctdd_argmax": ([_P, _I, _I, _I, _P, _P], _I),
     "ctdd_initial_samples": ([_P, _U64, _U64, _I, _I, _I, _P, _P], _I),
     "ctdd_philox_uniform": ([_U64, _U64, _I64, _I, _P, _P], _I),
@@ -216,6 +218,25 @@ def midpoint_predict(branch, logit_type, logits, x, qt0, base_rate, beta, eps, h
                                       _ptr(qt0, f32, "qt0"), _ptr(base_rate, f32, "base_rate"), float(beta),
                                       float(eps), float(h), N, D, S, _ptr(out), _stream())
     _check(rc, "ctdd_midpoint_predict")
+    return out
+
+
+def lbjf_from_rates(rates, x, h, E=None, seed=0, offset=0, want_probs=False, changed=None):
+    """LBJF posterior + draw on masked reverse rates (N, D, S) that are already computed (tauleap_step_s256(want_rates=True))."""
+    N, D, S = rates.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    probs = torch.empty_like(rates) if want_probs else None
+    rc = load().ctdd_lbjf_from_rates(_ptr(rates, f32, "rates"), _ptr(x, i32, "x"), float(h), _ptr(E, f32, "E"), seed, offset,
+                                     N, D, S, _ptr(out), _ptr(probs), _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_lbjf_from_rates")
+    return (out, probs) if want_probs else out
+
+
+def midpoint_from_rates(rates, x, h):
+    N, D, S = rates.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    rc = load().ctdd_midpoint_from_rates(_ptr(rates, f32, "rates"), _ptr(x, i32, "x"), float(h), N, D, S, _ptr(out), _stream())
+    _check(rc, "ctdd_midpoint_from_rates")
     return out
 
 

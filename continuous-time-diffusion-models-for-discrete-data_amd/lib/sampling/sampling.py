@@ -115,6 +115,16 @@ class _GridSampler:
         return native.tauleap_step(self.branch, self.logit_type, logits, x, q_i, model.process.base_rate, beta,
                                    self.eps_ratio, h, flags, key, offset, x_base=x_base, changed=changed)
 
+    def _lbjf(self, model, logits, x, q_i, fast, i, beta, h, flags, key, offset, changed=None):
+        """One Euler / LBJF step; at S = 256 the reverse rates come from the matrix-core kernel, the posterior and the
+        categorical draw run on them."""
+        if fast is not None:
+            _, rates = native.tauleap_step_s256(logits, x, fast, i, beta, h, flags & native.STEP_CORRECTOR, key, offset,
+                                                want_rates=True, want_x=False)
+            return native.lbjf_from_rates(rates, x, h, None, key, offset, changed=changed)
+        return native.lbjf_step(self.branch, self.logit_type, logits, x, q_i, model.process.base_rate, beta, self.eps_ratio,
+                                h, flags, None, key, offset, changed=changed)
+
     @staticmethod
     def _t_ones(t32, i, N, device):
         return torch.full((N,), float(t32[i]), device=device, dtype=torch.float32)
@@ -196,20 +206,18 @@ class LBJF(_GridSampler):
             ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
             t32, qt0, betas = self._tables(model, ts[:-1])
             changed = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
-            base_rate = model.process.base_rate
+            fast = self._fast_tables(model, qt0)
             sub = 1 + max(int(self.num_corrector_steps), 0)
             for i, t in enumerate(ts[:-1]):
                 h = float(np.float32(ts[i] - ts[i + 1]))
                 t_ones = self._t_ones(t32, i, N, dev)
                 q_i = qt0[i] if qt0 is not None else None
                 logits = model(x.long(), t_ones).float().contiguous()
-                x = native.lbjf_step(self.branch, self.logit_type, logits, x, q_i, base_rate, betas[i], self.eps_ratio,
-                                     h, 0, None, key, i * sub, changed=changed[i:i + 1])
+                x = self._lbjf(model, logits, x, q_i, fast, i, betas[i], h, 0, key, i * sub, changed=changed[i:i + 1])
                 if t <= self.corrector_entry_time:
                     for c in range(self.num_corrector_steps):
                         logits = model(x.long(), t_ones).float().contiguous()
-                        x = native.lbjf_step(self.branch, self.logit_type, logits, x, q_i, base_rate, betas[i],
-                                             self.eps_ratio, h, native.STEP_CORRECTOR, None, key, i * sub + 1 + c)
+                        x = self._lbjf(model, logits, x, q_i, fast, i, betas[i], h, native.STEP_CORRECTOR, key, i * sub + 1 + c)
             if self.loss_name == "CTElbo":
                 x = self._final_argmax(model, x, N)
             return x.cpu().numpy().astype(int), (changed.cpu().numpy() / N).tolist()
@@ -248,6 +256,7 @@ class MidPointTauL(_GridSampler):
             q_half = pr.tables(t32_half, want_qt0=True)[0] if need_q else None
             b_full, b_half = pr.beta(t32).tolist(), pr.beta(t32_half).tolist()
             fast_half = self._fast_tables(model, q_half)
+            fast_full = self._fast_tables(model, q_full)
             cnt = torch.zeros(3, nst, dtype=torch.int32, device=dev)      # first / final / 1to2 changes
             flags = (native.STEP_ORDINAL if self.is_ordinal else 0) | native.STEP_COUNT_RAW
             hf = float(np.float32(h))
@@ -255,9 +264,14 @@ class MidPointTauL(_GridSampler):
                 t_ones = torch.full((N,), float(t32[i]), device=dev)
                 t_05 = torch.full((N,), float(t32_half[i]), device=dev)
                 logits = model(x.long(), t_ones).float().contiguous()
-                x_prime = native.midpoint_predict(self.branch, self.logit_type, logits, x,
-                                                  q_full[i] if need_q else None, pr.base_rate, b_full[i],
-                                                  self.eps_ratio, h)
+                if fast_full is not None:           # S = 256: rates from the matrix-core kernel, drift on them
+                    _, rates = native.tauleap_step_s256(logits, x, fast_full, i, b_full[i], hf, 0, key, 0, want_rates=True,
+                                                        want_x=False)
+                    x_prime = native.midpoint_from_rates(rates, x, h)
+                else:
+                    x_prime = native.midpoint_predict(self.branch, self.logit_type, logits, x,
+                                                      q_full[i] if need_q else None, pr.base_rate, b_full[i],
+                                                      self.eps_ratio, h)
                 logits_p = model(x_prime.long(), t_05).float().contiguous()
                 x_new = self._leap(model, logits_p, x, q_half[i] if need_q else None, fast_half, i, b_half[i], hf,
                                    flags, key, i, x_base=x_prime, changed=cnt[1, i:i + 1])
@@ -303,11 +317,11 @@ class PCTauL(_GridSampler):
                     qc = pr.tables(tc, want_qt0=True)[0][0]
                     bc = float(pr.beta(tc)[0])
                     t_c = torch.full((N,), float(tc[0]), device=dev)
+                    fast_c = self._fast_tables(model, qc.unsqueeze(0)) if fast is not None else None
                     for c in range(s.num_corrector_steps):
                         logits = model(x.long(), t_c).float().contiguous()
-                        x = native.tauleap_step(self.branch, "direct", logits, x, qc, pr.base_rate, bc, s.eps_ratio,
-                                                float(np.float32(s.corrector_step_size_multiplier * h)),
-                                                native.STEP_ORDINAL | native.STEP_CORRECTOR, key, i * sub + 1 + c)
+                        x = self._leap(model, logits, x, qc, fast_c, 0, bc, float(np.float32(s.corrector_step_size_multiplier * h)),
+                                       native.STEP_ORDINAL | native.STEP_CORRECTOR, key, i * sub + 1 + c)
             x = self._final_argmax(model, x, N)
             return x.cpu().numpy().astype(int)
 

@@ -136,6 +136,14 @@ int ctdd_midpoint_predict(int branch, int logit_type, const float* logits, const
                           const float* qt0, const float* base_rate, float beta, float eps, float h,
                           int N, int D, int S, int32_t* out_x, void* stream);
 
+/* K7 / K8 on reverse rates that are already computed and masked -- rates (N,D,S) as written by ctdd_tauleap_step_s256's
+ * out_rates (corrector term included there when asked for): the LBJF posterior + categorical draw (sampling.py:278-293)
+ * and the midpoint predictor (417-453).  The S = 256 Euler / midpoint samplers take their S x S contraction from the
+ * matrix-core kernel this way instead of the generic fp32 one. */
+int ctdd_lbjf_from_rates(const float* rates, const int32_t* x, float h, const float* E, uint64_t seed, uint64_t offset,
+                         int N, int D, int S, int32_t* out_x, float* out_probs, int32_t* out_changed, void* stream);
+int ctdd_midpoint_from_rates(const float* rates, const int32_t* x, float h, int N, int D, int S, int32_t* out_x, void* stream);
+
 /* K10 final denoise: argmax_s softmax(logits) = first argmax of logits (sampling.py:223-229). */
 int ctdd_argmax(const float* logits, int N, int D, int S, int32_t* out_x, void* stream);
 

@@ -173,3 +173,37 @@ def test_crm_fused_step_matches_generic_and_replay(env, flags):
     assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 3e-3
     assert int(changed.item()) == int((out != x).sum())
     assert (out != x).float().mean() > 0.05
+
+
+@pytest.mark.parametrize("branch", ["ctelbo", "crm"])
+def test_lbjf_and_midpoint_on_matrix_core_rates(env, branch):
+    """S = 256 Euler (LBJF) step and midpoint predictor with the reverse rates taken from the matrix-core kernel
+    (ctdd_lbjf_from_rates / ctdd_midpoint_from_rates) against the generic fp32 kernels on the same Philox stream."""
+    native, pr, op = env
+    N, D = 3, 211
+    logits, x = _case(N, D, 21, 2.0)
+    tt = torch.tensor([0.35])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    crm = branch == "crm"
+    tabs = native.S256Tables(qt0, pr.base_rate, 0.0 if crm else 1e-9, crm=crm)
+    br, lt = (native.BRANCH_CRM, "reverse_prob") if crm else (native.BRANCH_CTELBO, "direct")
+    dl, dx = logits.cuda().contiguous(), x.to(torch.int32).cuda()
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = (ops.reverse_rates_crm("reverse_prob", logits, x, q, r) if crm else ops.reverse_rates_ctelbo(logits, x, q, r, 1e-9))[0]
+    h = float(0.5 / ops.zero_own_state(rr, x).sum(-1).median())
+    for flags in (0, native.STEP_CORRECTOR):
+        _, rates = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 9, 4, want_rates=True, want_x=False)
+        changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+        got, probs = native.lbjf_from_rates(rates, dx, h, None, 9, 4, want_probs=True, changed=changed)
+        ref, rprobs = native.lbjf_step(br, lt, dl, dx, qt0[0], pr.base_rate, beta, 1e-9, h, flags, None, 9, 4, want_probs=True)
+        # (atol: the own-state entry 1 - h * sum(rates) cancels where h * sum ~ 1; the sums agree to 3e-5 relative)
+        np.testing.assert_allclose(probs.cpu().numpy(), rprobs.cpu().numpy(), rtol=2e-4, atol=5e-6)
+        assert (got != ref).float().mean().item() < 3e-3            # exponential-race near-ties only
+        assert int(changed.item()) == int((got != dx).sum())
+    _, rates = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, 0, 9, 4, want_rates=True, want_x=False)
+    xp = native.midpoint_from_rates(rates, dx, 4 * h)
+    xr = native.midpoint_predict(br, lt, dl, dx, qt0[0], pr.base_rate, beta, 1e-9, 4 * h)
+    diff = (xp != xr)
+    assert diff.float().mean().item() < 5e-3 and (xp - xr).abs().max().item() <= 1    # rounding of a drift that sits on .5
+    assert (xp != dx).float().mean().item() > 0.05
