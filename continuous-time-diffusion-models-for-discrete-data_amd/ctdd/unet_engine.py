@@ -224,7 +224,11 @@ class UNetEngine:
                 # measured at batch 256 (MNIST net): the LDS-DMA ring wins where 512-pixel tiles give >= 160
                 # workgroups and every unit has nine taps (28x28, 14x14); the patch kernel (128/256-pixel tiles, two
                 # workgroups per CU) elsewhere.  Split-K lost everywhere it was tried (fp32 atomics + finish pass).
-                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= int(getattr(m, "ring_min_tiles", 80)) and N % 96 == 0) else "patch"
+                ring_min = int(getattr(m, "ring_min_tiles", 80))
+                which = "ring" if (only3 and -(-M_ // 512) * -(-N // 96) >= ring_min and N % 96 == 0) else "patch"
+                # (CIFAR net, N = 256 at 16x16: 64-column ring tiles beat the 128-column patch tiles, 49 vs 54 / 69 vs 104 us at batch 128)
+                if which == "patch" and only3 and N % 64 == 0 and N % 96 != 0 and Hout * Wout <= 256 and -(-M_ // 512) * (N // 64) >= ring_min:
+                    which = "ring"
             resident = which == "res" and patchable and all(c % 32 == 0 for c in cs) and N % 32 == 0
             ring = which == "ring" and patchable and all(c % 16 == 0 for c in cs) and N % 32 == 0
             if resident or ring:
