@@ -1466,14 +1466,25 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnArgs a) {
       for (int k = 0; k < 4; ++k) {
         if (!ok[k]) continue;
         const unsigned w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
-        float y[8];
+        // two channels per instruction where the hardware has packed fp32 forms (fma, mul, add); exp2 / rcp stay scalar
+        using f2 = __attribute__((ext_vector_type(2))) float;
+        const float4 sc0 = *(const float4*)(scale + c0[k]), sc1 = *(const float4*)(scale + c0[k] + 4);
+        const float4 sh0 = *(const float4*)(shift + c0[k]), sh1 = *(const float4*)(shift + c0[k] + 4);
+        const f2 scv[4] = {{sc0.x, sc0.y}, {sc0.z, sc0.w}, {sc1.x, sc1.y}, {sc1.z, sc1.w}};
+        const f2 shv[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
+        unsigned ow[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = (j & 1) ? __uint_as_float(w[j >> 1] & 0xFFFF0000u) : __uint_as_float(w[j >> 1] << 16);
-          y[j] = fmaf(x, scale[c0[k] + j], shift[c0[k] + j]);
-          if (a.swish) y[j] = y[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-y[j]));       // hardware exp2 / rcp (1 ulp) before the bf16 rounding
+        for (int j = 0; j < 4; ++j) {
+          const f2 x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+          f2 y = __builtin_elementwise_fma(x, scv[j], shv[j]);
+          if (a.swish) {                                                  // y * 1 / (1 + 2^(-y log2 e)): hardware exp2 / rcp (1 ulp)
+            const f2 z = y * (f2){-1.4426950408889634f, -1.4426950408889634f};
+            const f2 d = (f2){__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + (f2){1.0f, 1.0f};
+            y = y * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+          }
+          ow[j] = pack2_bf16(y.x, y.y);
         }
-        *(uint4*)(a.out_hi + oo[k]) = make_uint4(pack2_bf16(y[0], y[1]), pack2_bf16(y[2], y[3]), pack2_bf16(y[4], y[5]), pack2_bf16(y[6], y[7]));
+        *(uint4*)(a.out_hi + oo[k]) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
       }
     }
     return;
