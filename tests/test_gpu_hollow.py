@@ -122,3 +122,49 @@ def test_attention_kernels_against_masked_softmax(hd, mode):
         assert (out_hi.float() - ref).abs().max().item() < max(tol, 2e-2), fn
         if fn is lib.ctdd_hollow_attention_bf16:
             assert (out_hi.float() + out_lo.float() - out).abs().max().item() < 1e-4       # hi + lo ~ fp32 value (2^-17 relative)
+
+
+def test_engine_follows_weight_updates():
+    """The engine caches packed weights and a captured plan; a fused optimizer step (raw-pointer writes) and the EMA swap of
+    eval() / train() must invalidate them: after a training step the eval-mode engine output equals the module path on the
+    NEW weights (and differs from the output before the step)."""
+    import lib.models.models  # noqa: F401
+    import lib.losses.losses  # noqa: F401
+    import lib.training.training  # noqa: F401
+    import lib.optimizers.optimizers  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.losses.losses_utils as lu
+    import lib.training.training_utils as tu
+    import lib.optimizers.optimizers_utils as ou
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    cfg = get_config()
+    cfg.device = "cuda"
+    cfg.optimizer.lr = 5e-2                                            # a visible step
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+    loss, step = lu.get_loss(cfg), tu.get_train_step(cfg)
+    D, S = int(cfg.model.concat_dim), cfg.data.S
+    x = torch.randint(0, S, (6, D), device="cuda")
+    t = torch.rand(6, device="cuda") * 0.8 + 0.1
+
+    def both():
+        model.eval()
+        with torch.no_grad():
+            cfg.model.engine = "hip"
+            eng = model(x, t).clone()
+            cfg.model.engine = "torch"
+            ref = model(x, t).clone()
+            cfg.model.engine = "hip"
+        model.train()
+        return eng, ref
+
+    e0, r0 = both()
+    assert (e0 - r0).abs().max().item() < 2e-4 * max(r0.abs().max().item(), 1.0)
+    mb = torch.randint(0, S, (16, D), device="cuda")
+    for _ in range(3):
+        step.step(state, loss, mb)
+        state["n_iter"] += 1
+    e1, r1 = both()
+    assert (e1 - r1).abs().max().item() < 2e-4 * max(r1.abs().max().item(), 1.0)    # the engine sees the new (EMA) weights
+    assert (r1 - r0).abs().max().item() > 1e-2 * max(r1.abs().max().item(), 1.0)    # ... which did change
