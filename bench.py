@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU (SURVEY 8d: 256)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode timing")
     ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
     ap.add_argument("--model-opt", action="append", default=[], help="integer engine option, key=value (tuning sweeps)")
     return ap.parse_args()
@@ -69,12 +70,13 @@ def build_model(device):
     return cfg, model, sampler
 
 
-def kernel_roofline(sampler, st, steps, batch):
+def kernel_roofline(sampler, st, steps, batch, restore_state=False):
     """Mean duration of the fused tau-leap launch alone, HIP events on the launch stream, over the
     same steps (logits recomputed outside the event bracket)."""
     from ctdd import native
     model = st.model
     times = []
+    x_keep = st.x
     for i in steps:
         t_ones = sampler._t_ones(st.t32, i, st.N, st.dev)
         logits = model(st.x.long(), t_ones).float().contiguous()
@@ -87,6 +89,8 @@ def kernel_roofline(sampler, st, steps, batch):
         e1.synchronize()
         times.append(e0.elapsed_time(e1) * 1e-3)
     dur = float(np.mean(times))
+    if restore_state:
+        st.x = x_keep
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_tauleap_s256.json")
     if batch == 256 and os.path.exists(pmc):          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload)
@@ -136,19 +140,42 @@ def network_roofline(model, batch):
     # the forward as it runs in the timed loop (HIP-graph replay, sub-batches on parallel streams, all kernels of the network)
     x = torch.randint(0, S, (batch, D), device=next(model.parameters()).device)
     t = torch.full((batch,), 0.5, device=x.device)
-    model(x, t)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
+    from lib.models.models import borrow_engine_output
+    with borrow_engine_output(model):          # as the sampler loop calls it: the plan's own output buffer, no copy
         model(x, t)
-    e1.record()
-    e1.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            model(x, t)
+        e1.record()
+        e1.synchronize()
     fwd = e0.elapsed_time(e1) * 1e-3 / 10
     ach = flops / fwd / 1e12
     return {"kernel": "score-network forward: ctdd k_conv_ring / k_conv_patch / k_conv_igemm bf16 implicit-GEMM convolutions (+ GroupNorm, attention, time MLP)",
             "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5),
             "traffic": None, "forward_ms": round(fwd * 1e3, 3), "matrix_gflop_per_forward": round(flops / 1e9, 1), "sub_batches": len(plans),
             "conv_launches_per_forward": n, "conv_launches_sequential_tflops": round(seq, 2), "conv_launches_sequential_us": round(secs * 1e6, 1)}
+
+
+def fp32_parity_mode(cfg, model, sampler, batch, steps=6, warmup=2):
+    """The same sampler step with the score network in its parity mode (`engine_precision="fp32"`: exact-fp32 matrix
+    instructions, the mode that meets the 1e-4 logit bar against the reference's golden logits, tests/test_gpu_unet.py)."""
+    prev_prec, prev_eng = getattr(cfg.model, "engine_precision", "bf16"), model._engine
+    cfg.model.engine_precision, model._engine = "fp32", None
+    try:
+        st = sampler.begin(model, batch)
+        for i in range(warmup):
+            sampler.advance(st, i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            sampler.advance(st, i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        cfg.model.engine_precision, model._engine = prev_prec, prev_eng
+    return {"value": round(batch * steps / el, 2), "unit": "sample-steps/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+            "dtype": "f32", "note": "score network on v_mfma_f32_32x32x2_f32 (logits within 1e-4 of the reference's goldens); same fused tau-leap launch"}
 
 
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
@@ -243,7 +270,11 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         roof = kernel_roofline(sampler, st, range(W + K, min(W + K + 20, sampler.num_steps - 1)), a.batch) if rank == 0 else None
+        # the same kernel mid-trajectory (t ~ 0.5: fewer dimensions jump than next to t = 1, where the timed steps run)
+        mid = sampler.num_steps // 2
+        roof_mid = kernel_roofline(sampler, st, range(mid, mid + 20), a.batch, restore_state=True) if rank == 0 else None
         roof_net = network_roofline(model, a.batch) if rank == 0 else None
+        fp32_mode = fp32_parity_mode(cfg, model, sampler, a.batch) if (rank == 0 and world == 1 and not a.no_fp32_mode) else None
     if rank == 0:
         value = a.batch * K * world / el
         line = {
@@ -257,6 +288,8 @@ def main():
             "dims_per_s": round(value * D, 1),
             "roofline": roof,
             "roofline_network": roof_net,
+            "roofline_mid_trajectory": None if roof_mid is None else {k_: roof_mid[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "mfma_view")},
+            "fp32_parity_mode": fp32_mode,
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, cfg, a.cpu_batch)

@@ -27,6 +27,19 @@ inline int finish_launch(const char* what) {
   return CTDD_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: raise it to the CU's 160 KiB once per
+// (device, kernel instantiation) -- `done` is the call site's static flag array -- so that a later launch of the same
+// instantiation with a larger LDS request (another resolution, a second model) or on another GPU of the process is covered.
+// Called before the launch, never inside a stream capture for the first time (the engines warm every plan up eagerly).
+inline void ensure_lds_ceiling(const void* kernel, bool (&done)[16]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (!done[dev]) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done[dev] = true;
+  }
+}
+
 constexpr int WAVE = 64;
 
 // ---------------------------------------------------------------- Philox4x32-10 (oracle/philox.py)

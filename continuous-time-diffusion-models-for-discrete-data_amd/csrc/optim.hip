@@ -72,6 +72,39 @@ using namespace ctdd;
 
 extern "C" int ctdd_opt_chunk_elems(void) { return OPT_CHUNK; }
 
+// The two launches separately, for callers whose tensors fall into several tables (param groups with different
+// hyper-parameters, parameters whose Adam step counts differ): ONE gradient norm over all tables, then one update per table.
+extern "C" int ctdd_grad_sumsq(const void* tensors, const void* chunks, int nchunks, double* sumsq_scratch, int zero_first,
+                               void* stream) {
+  CTDD_REQUIRE(tensors && chunks && nchunks > 0 && sumsq_scratch, CTDD_EINVAL, "grad sumsq: null table / scratch");
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_first && hipMemsetAsync(sumsq_scratch, 0, sizeof(double), st) != hipSuccess) return finish_launch("memset");
+  hipLaunchKernelGGL(k_grad_sumsq, dim3(nchunks), dim3(256), 0, st, (const OptTensor*)tensors, (const OptChunk*)chunks,
+                     sumsq_scratch);
+  return finish_launch("k_grad_sumsq");
+}
+
+static int adam_apply(const void* tensors, const void* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                      int64_t step, float max_norm, float ema_decay, const double* sumsq, hipStream_t st) {
+  AdamArgs a;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.lr_over_bc1 = (float)((double)lr / bc1);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+  a.ema_w = ema_decay >= 0.0f ? 1.0f - ema_decay : -1.0f;
+  hipLaunchKernelGGL(k_adam_ema, dim3(nchunks), dim3(256), 0, st, (const OptTensor*)tensors, (const OptChunk*)chunks, sumsq, a);
+  return finish_launch("k_adam_ema");
+}
+
+extern "C" int ctdd_adam_ema_apply(const void* tensors, const void* chunks, int nchunks, float lr, float beta1, float beta2,
+                                   float eps, int64_t step, float max_norm, float ema_decay, const double* sumsq,
+                                   void* stream) {
+  CTDD_REQUIRE(tensors && chunks && nchunks > 0 && (sumsq || max_norm <= 0.0f), CTDD_EINVAL, "adam apply: null table / norm");
+  CTDD_REQUIRE(step >= 1 && beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, CTDD_EINVAL,
+               "adam apply: step=%lld beta=(%g,%g)", (long long)step, (double)beta1, (double)beta2);
+  return adam_apply(tensors, chunks, nchunks, lr, beta1, beta2, eps, step, max_norm, ema_decay, sumsq, (hipStream_t)stream);
+}
+
 extern "C" int ctdd_adam_ema_step(const void* tensors, const void* chunks, int nchunks, float lr, float beta1, float beta2,
                                   float eps, int64_t step, float max_norm, float ema_decay, double* sumsq_scratch,
                                   void* stream) {
@@ -85,13 +118,5 @@ extern "C" int ctdd_adam_ema_step(const void* tensors, const void* chunks, int n
                        sumsq_scratch);
     if (int rc = finish_launch("k_grad_sumsq")) return rc;
   }
-  AdamArgs a;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.lr_over_bc1 = (float)((double)lr / bc1);
-  a.bc2_sqrt = (float)sqrt(bc2);
-  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
-  a.ema_w = ema_decay >= 0.0f ? 1.0f - ema_decay : -1.0f;
-  hipLaunchKernelGGL(k_adam_ema, dim3(nchunks), dim3(256), 0, st, (const OptTensor*)tensors, (const OptChunk*)chunks,
-                     (const double*)sumsq_scratch, a);
-  return finish_launch("k_adam_ema");
+  return adam_apply(tensors, chunks, nchunks, lr, beta1, beta2, eps, step, max_norm, ema_decay, sumsq_scratch, st);
 }

@@ -406,10 +406,11 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   T = grp_sum(T, G);
   const float Lam = T * a.h;
   const bool ordinal = a.flags & CTDD_STEP_ORDINAL;
-  int jump = 0;
+  int jump = 0, njumps = 0;                                   // njumps: jump events drawn for this dimension (sum_s k_s)
   if (Lam > 0.0f && Lam <= SUPERPOSE_MAX_LAMBDA) {
     PhiloxStream rng(a.seed, a.offset, (uint64_t)rowc, 0u);   // identical in every lane of the row
     const int K = poisson_row(Lam, rng);
+    njumps = K;
     if (K > 0 && (ordinal || K == 1)) {
       // inclusive prefix sums of rr in s order (s = li + k*G)
       float c[EPT], carry = 0.0f;
@@ -461,12 +462,17 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     for (int o = G >> 1; o >= 1; o >>= 1) jl += __shfl_xor(jl, o, WAVE);
     jl = jl > S ? S : (jl < -S ? -S : jl);                    // |jump| >= S - 1 saturates the state clamp either way
     jump = (ordinal || cnt <= 1) ? (int)jl : 0;
+    njumps = cnt;
   }
   if (live && li == 0) {
     const int xn = min(max(xcur + jump, 0), S - 1);
     a.out_x[row] = xn;
     const bool moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
     if (a.out_changed && moved) atomicAdd(a.out_changed, 1);
+    if (a.out_changed && (a.flags & CTDD_STEP_COUNT_JUMPS)) {  // sampling.py:489-495: dimensions with >= 1 and with > 1 jump events
+      if (njumps > 0) atomicAdd(a.out_changed + 1, 1);
+      if (njumps > 1) atomicAdd(a.out_changed + 2, 1);
+    }
   }
   }  // rows of this wave
 }

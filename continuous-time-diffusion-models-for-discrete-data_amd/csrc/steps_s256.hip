@@ -379,10 +379,11 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
   const float Lam = scale * T * a.h;
   const bool ordinal = a.flags & CTDD_STEP_ORDINAL;
   const uint64_t rngrow = (uint64_t)(live ? myrow : a.R - 1);
-  int jump = 0;
+  int jump = 0, njumps = 0;               // njumps: jump events drawn for this dimension (sum_s k_s)
   if (Lam > 0.0f && Lam <= SUPERPOSE_MAX_LAMBDA) {
     PhiloxStream rng(a.seed, a.offset, rngrow, 0u);             // both lanes of the pair: same stream
     const int K = poisson_row(Lam, rng);
+    njumps = K;
     if (K > 0 && (ordinal || K == 1)) {
       // cumulative rates in destination order (block of 8 = g0's four then g1's four), written
       // back over the lane's own LDS column; the ends of the lane's 32 blocks stay in registers
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
     jl += __shfl_xor(jl, 32, WAVE);
     jl = jl > S256 ? S256 : (jl < -S256 ? -S256 : jl);        // |jump| >= S - 1 saturates the state clamp either way
     jump = (ordinal || cnt <= 1) ? (int)jl : 0;
+    njumps = cnt;
   }
   STAMP(4)
 #ifdef CTDD_S256_STAMPS
@@ -473,6 +475,12 @@ __global__ __launch_bounds__(256, 1) void k_tauleap_s256(const S256Args a) {
   if (a.out_changed) {                       // one atomic per wave instead of one per row on a single address
     const int nmoved = __builtin_popcountll(__ballot(moved));
     if (lane == 0 && nmoved) atomicAdd(a.out_changed, nmoved);
+    if (a.flags & CTDD_STEP_COUNT_JUMPS) {   // sampling.py:489-495: dimensions with >= 1 and with > 1 jump events
+      const int n1 = __builtin_popcountll(__ballot(live && g == 0 && njumps > 0));
+      const int n2 = __builtin_popcountll(__ballot(live && g == 0 && njumps > 1));
+      if (lane == 0 && n1) atomicAdd(a.out_changed + 1, n1);
+      if (lane == 0 && n2) atomicAdd(a.out_changed + 2, n2);
+    }
   }
 }
 
@@ -521,11 +529,8 @@ extern "C" int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, con
   a.R = (int64_t)N * D; a.out_rates = out_rates; a.out_x = out_x; a.out_changed = out_changed;
   const int64_t grid = (a.R + TILE_ROWS - 1) / TILE_ROWS;
   CTDD_REQUIRE(grid < (1ll << 31), CTDD_ERANGE, "too many rows");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_tauleap_s256, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    attr_set = true;
-  }
+  static bool attr_done[16] = {};
+  ensure_lds_ceiling((const void*)k_tauleap_s256, attr_done);
   hipLaunchKernelGGL(k_tauleap_s256, dim3((unsigned)grid), dim3(256), 163840, (hipStream_t)stream, a);
   return finish_launch("k_tauleap_s256");
 }

@@ -1703,11 +1703,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (lds < stats_lds) lds = stats_lds;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   dim3 g((unsigned)((M + BM - 1) / BM), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)));
-  static bool attr_done = false;            // once per instantiation (not legal inside stream capture)
-  if (lds > 48 * 1024 && !attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_conv_igemm<BK, BNT, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static bool attr_done[16] = {};
+  ensure_lds_ceiling((const void*)k_conv_igemm<BK, BNT, F32>, attr_done);
   hipLaunchKernelGGL((k_conv_igemm<BK, BNT, F32>), g, dim3(256), lds, st, a);
   return finish_launch("k_conv_igemm");
 }
@@ -1739,11 +1736,8 @@ static int launch_patch(const ConvArgs& a, hipStream_t st) {
   if (lds < epi_lds) lds = epi_lds;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   dim3 g((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), a.ksplit > 1 ? a.ksplit : 1);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_conv_patch<BK, BNT, WM, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static bool attr_done[16] = {};
+  ensure_lds_ceiling((const void*)k_conv_patch<BK, BNT, WM, EXT>, attr_done);
   hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM, EXT>), g, dim3(256), lds, st, a);
   if (int rc = finish_launch("k_conv_patch")) return rc;
   if (a.ksplit > 1) {
@@ -1790,11 +1784,8 @@ static int launch_res(const ConvArgs& a, hipStream_t st) {
   const size_t epi_lds = epilogue_rows_lds(8, BNT, 512, a.H * a.W);
   if (lds < epi_lds) lds = epi_lds;
   CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "resident conv: %zu bytes of LDS", lds);
-  static bool attr_done = false;               // not inside a stream capture: set once per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_conv_res<BNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static bool attr_done[16] = {};
+  ensure_lds_ceiling((const void*)k_conv_res<BNT>, attr_done);
   hipLaunchKernelGGL((k_conv_res<BNT>), g, dim3(512), lds, st, a);
   if (int rc = finish_launch("k_conv_res")) return rc;
   if (nz > 1) {
@@ -1839,11 +1830,8 @@ static int launch_ring(const ConvArgs& a, hipStream_t st) {
   const size_t epi_lds = epilogue_rows_lds(NW, BNT, BMP, a.H * a.W);
   if (lds < epi_lds) lds = epi_lds;
   CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "ring conv: %zu bytes of LDS", lds);
-  static bool attr_done = false;               // not inside a stream capture: set once per instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k_conv_ring<BNT, NBUF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static bool attr_done[16] = {};
+  ensure_lds_ceiling((const void*)k_conv_ring<BNT, NBUF, NW>, attr_done);
   hipLaunchKernelGGL((k_conv_ring<BNT, NBUF, NW>), g, dim3(NW * 64), lds, st, a);
   if (int rc = finish_launch("k_conv_ring")) return rc;
   if (nz > 1) {

@@ -22,7 +22,7 @@ import math
 import torch
 
 from . import native
-from .unet_engine import _ConvArgs, _lib as _unet_lib, SEG_1x1
+from .unet_engine import _ConvArgs, _lib as _unet_lib, _unwrap, SEG_1x1
 
 _P, _I, _F, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -61,7 +61,7 @@ def _lib():
 
 
 def supports(model):
-    net = getattr(model, "net", None)
+    net = _unwrap(getattr(model, "net", None))
     if net is None or net.__class__.__name__ != "BidirectionalTransformer2":
         return False
     m = net.config.model
@@ -72,8 +72,8 @@ def supports(model):
 
 class HollowEngine:
     def __init__(self, model, precision=None):
-        self.model, self.net = model, model.net
-        self.precision = precision or getattr(model.net.config.model, "engine_precision", "bf16x3")
+        self.model, self.net = model, _unwrap(model.net)
+        self.precision = precision or getattr(self.net.config.model, "engine_precision", "bf16x3")
         if self.precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError(f"unknown engine precision {self.precision}")
         # "fp32": exact-fp32 matrix instructions and fp32 FMA attention; "bf16": bf16 operands (~1e-3 absolute on the logits);

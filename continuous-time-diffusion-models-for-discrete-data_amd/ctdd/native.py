@@ -16,7 +16,7 @@ _LIB = None
 
 BRANCH_CTELBO, BRANCH_CRM = 0, 1
 LOGIT_TYPES = {"direct": 0, "reverse_prob": 1, "reverse_logscale": 2}
-STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM = 1, 2, 4, 8
+STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM, STEP_COUNT_JUMPS = 1, 2, 4, 8, 16
 
 
 class CtddError(RuntimeError):
@@ -56,6 +56,8 @@ _SIGS = {
     "ctdd_score_elbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_opt_chunk_elems": ([], _I),
     "ctdd_adam_ema_step": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
+    "ctdd_grad_sumsq": ([_P, _P, _I, _P, _I, _P], _I),
+    "ctdd_adam_ema_apply": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
 }
 UNET_EXPORTS = ("ctdd_unet_conv", "ctdd_unet_conv_patch", "ctdd_unet_conv_res", "ctdd_unet_conv_ring", "ctdd_unet_upsample2x", "ctdd_unet_first_conv", "ctdd_unet_gn_apply", "ctdd_unet_channel_stats",
                 "ctdd_unet_time", "ctdd_unet_attention", "ctdd_unet_logistic_head")    # bound in ctdd/unet_engine.py

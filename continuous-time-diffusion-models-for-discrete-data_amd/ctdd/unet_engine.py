@@ -77,11 +77,21 @@ def _lib():
     return lib
 
 
+def _unwrap(net):
+    """cfg.distributed wraps the network in DistributedDataParallel (models.py:104-107); the engine reads the module behind it."""
+    return net.module if hasattr(net, "module") and net.__class__.__name__ == "DistributedDataParallel" else net
+
+
 def supports(model):
     """The engine covers the reference's image U-Net wrapper without padding."""
-    net = getattr(model, "net", None)
+    net = _unwrap(getattr(model, "net", None))
     return (net is not None and net.__class__.__name__ == "UNet" and not model.padding
             and model.cfg.model.model_output in ("logits", "logistic_pars"))
+
+
+def training_supported(model):
+    """Whether the hand-written training plan (forward that keeps what backward needs + HIP backward) covers this model."""
+    return False
 
 
 class _Tensor:
@@ -100,7 +110,7 @@ class _Tensor:
 class UNetEngine:
     def __init__(self, model, precision=None):
         self.model = model
-        self.net = model.net
+        self.net = _unwrap(model.net)
         self.cfg = model.cfg
         self.dev = next(self.net.parameters()).device
         if self.dev.type != "cuda":
@@ -477,7 +487,11 @@ class UNetEngine:
                 with torch.cuda.graph(g):
                     self._run_plan(st)
                 st.graph = g
-            except Exception:                 # capture unsupported: keep eager launches
+            except native.CtddError:          # a kernel refused its arguments: never hide that
+                raise
+            except RuntimeError as e:         # stream capture refused (a HIP error, not a kernel-argument error): eager launches
+                import warnings
+                warnings.warn(f"[ctdd] UNetEngine: HIP-graph capture failed ({e}); the plan runs as eager launches", RuntimeWarning)
                 st.graph = None
                 torch.cuda.synchronize()
         return st

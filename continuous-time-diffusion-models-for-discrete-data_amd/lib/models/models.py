@@ -5,6 +5,8 @@ A model is callable `model(x, t) -> (B, D, S)` fp32 logits and exposes `.transit
 .rate_mat/.transit_between`, `.device`, `.S`, `.update_ema()`, EMA-swapping `.train()/.eval()` and a
 `state_dict()` carrying `ema_decay / ema_num_updates / ema_shadow_params`, as the reference does.
 Only the wrappers named by the BASELINE configs are built (SURVEY section 2 #3)."""
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -13,6 +15,36 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 import lib.models.model_utils as model_utils
 from lib.models.forward_model import GaussianTargetRate, UniformRate, UniformVariantRate, BirthDeathForwardBase  # noqa: F401
 from lib.networks import unet
+
+
+def unwrap(net):
+    """The module behind a DistributedDataParallel wrapper (cfg.distributed, models.py:104-107)."""
+    return net.module if isinstance(net, DDP) else net
+
+
+def _warn_once(model, key, msg):
+    """A fallback to torch device ops is never silent: one warning per model and reason."""
+    seen = model.__dict__.setdefault("_fallback_warned", set())
+    if key not in seen:
+        seen.add(key)
+        warnings.warn(f"[ctdd] {model.__class__.__name__}: {msg}", RuntimeWarning, stacklevel=3)
+
+
+class borrow_engine_output:
+    """`with borrow_engine_output(model):` -- inside, model(x, t) returns the engine plan's own logits buffer
+    (no copy); the next forward overwrites it.  The sampler loops consume logits within a step and use this."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        self.prev = getattr(self.model, "_borrow_engine_output", False)
+        self.model._borrow_engine_output = True
+        return self.model
+
+    def __exit__(self, *exc):
+        self.model._borrow_engine_output = self.prev
+        return False
 
 
 def _maybe_ddp(net, cfg, rank):
@@ -89,23 +121,34 @@ class ImageX0PredBasePaul(nn.Module):
             logits = logits[:, :, :-1, :-1, :]
         return logits.reshape(B, D, self.S)
 
-    # -- hand-written HIP inference engine (ctdd/unet_engine.py); training keeps autograd ops
+    # -- hand-written HIP engine (ctdd/unet_engine.py): inference plan under no_grad/eval, training plan
+    #    (forward that saves what backward needs + hand-written backward) when gradients are on
     def _use_engine(self, x):
-        if torch.is_grad_enabled() or self.training or not x.is_cuda or self.cfg.distributed:
-            return False
         if getattr(self.cfg.model, "engine", "hip") != "hip":
+            return False                                   # explicit opt-out (cfg.model.engine = "torch")
+        if not x.is_cuda:
+            return False                                   # cfg.device == "cpu": the reference's host path
+        from ctdd import unet_engine
+        if not unet_engine.supports(self):
+            _warn_once(self, "unet", "U-Net variant outside the HIP engine's coverage (padding / model_output); running torch device ops")
             return False
-        try:
-            from ctdd import unet_engine
-        except ImportError:
+        if x.dtype not in (torch.int64, torch.int32):
+            _warn_once(self, "unet-dtype", f"HIP engine takes integer states, got {x.dtype}; running torch device ops")
             return False
-        return unet_engine.supports(self)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            return unet_engine.training_supported(self)
+        return True
 
     def _engine_forward(self, x, times):
         from ctdd import unet_engine
         if self._engine is None:
             self._engine = unet_engine.UNetEngine(self)
-        return self._engine(x, times)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            return self._engine.train_forward(x, times)
+        out = self._engine(x, times)
+        # the plan owns its output buffer: hand out a copy unless the caller (a sampler loop that consumes the
+        # logits before the next forward) asked to borrow it -- two live results must not alias
+        return out if getattr(self, "_borrow_engine_output", False) else out.clone()
 
 
 class HollowTransformer(nn.Module):
@@ -130,17 +173,24 @@ class HollowTransformer(nn.Module):
                 # contraction: ~1e-5 of the logit range from the fp32 module, 2.3x its speed), "fp32" (exact-fp32 matrix
                 # instructions, ~2e-6), "bf16" (single bf16 operands: ~5e-3, 3.4x)
                 self._engine = hollow_engine.HollowEngine(self, precision=getattr(self.cfg.model, "engine_precision", None))
-            return self._engine(x, times)
+            out = self._engine(x, times)
+            return out if getattr(self, "_borrow_engine_output", False) else out.clone()
         return self.net(x, times)
 
     # -- hand-written HIP inference engine (ctdd/hollow_engine.py); training keeps autograd ops
     def _use_engine(self, x):
-        if torch.is_grad_enabled() or self.training or not x.is_cuda or x.dtype not in (torch.int64, torch.int32):
+        if getattr(self.cfg.model, "engine", "hip") != "hip" or not x.is_cuda:
             return False
-        if getattr(self.cfg.model, "engine", "hip") != "hip":
+        if torch.is_grad_enabled() or self.training:
             return False
         from ctdd import hollow_engine
-        return hollow_engine.supports(self)
+        if x.dtype not in (torch.int64, torch.int32):
+            _warn_once(self, "hollow-dtype", f"HIP engine takes integer states, got {x.dtype}; running torch device ops")
+            return False
+        if not hollow_engine.supports(self):
+            _warn_once(self, "hollow", "hollow-transformer variant outside the HIP engine's coverage; running torch device ops")
+            return False
+        return True
 
 
 class EMA:

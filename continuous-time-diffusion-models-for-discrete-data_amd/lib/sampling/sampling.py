@@ -16,6 +16,7 @@ import torch
 import lib.sampling.sampling_utils as sampling_utils
 from ctdd import native
 from lib.models.model_utils import get_logprob_with_logits  # noqa: F401  (re-exported like the reference)
+from lib.models.models import borrow_engine_output
 
 _CTELBO_LOSSES = ("CTElbo", "NLL", "CTElboLambda")
 
@@ -159,6 +160,10 @@ class TauL(_GridSampler):
 
     def advance(self, st, i):
         """Step i of the grid: network forward, fused reverse-rate/jump/update launch, correctors."""
+        with borrow_engine_output(st.model):
+            self._advance(st, i)
+
+    def _advance(self, st, i):
         model, N = st.model, st.N
         t = st.ts[i]
         h = float(np.float32(st.ts[i] - st.ts[i + 1]))
@@ -180,7 +185,7 @@ class TauL(_GridSampler):
         return x.cpu().numpy().astype(int), (st.changed.cpu().numpy() / st.N).tolist()
 
     def sample(self, model, N):
-        with torch.no_grad():
+        with torch.no_grad(), borrow_engine_output(model):
             st = self.begin(model, N)
             for i in range(self.num_steps):
                 self.advance(st, i)
@@ -201,7 +206,7 @@ class LBJF(_GridSampler):
     def sample(self, model, N):
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad():
+        with torch.no_grad(), borrow_engine_output(model):
             x = self._initial(model, N, key, self.cfg.model.Q_sigma)
             ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
             t32, qt0, betas = self._tables(model, ts[:-1])
@@ -239,7 +244,7 @@ class MidPointTauL(_GridSampler):
     def sample(self, model, N):
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad():
+        with torch.no_grad(), borrow_engine_output(model):
             x = self._initial(model, N, key, self.cfg.model.Q_sigma)
             h = (self.max_t - self.min_t) / self.num_steps
             full, half, t = [], [], self.max_t
@@ -257,8 +262,9 @@ class MidPointTauL(_GridSampler):
             b_full, b_half = pr.beta(t32).tolist(), pr.beta(t32_half).tolist()
             fast_half = self._fast_tables(model, q_half)
             fast_full = self._fast_tables(model, q_full)
-            cnt = torch.zeros(3, nst, dtype=torch.int32, device=dev)      # first / final / 1to2 changes
-            flags = (native.STEP_ORDINAL if self.is_ordinal else 0) | native.STEP_COUNT_RAW
+            # per step: [final changes, dims with >= 1 jump event, dims with > 1, first-stage changes, 1to2 changes]
+            cnt = torch.zeros(nst, 5, dtype=torch.int32, device=dev)
+            flags = (native.STEP_ORDINAL if self.is_ordinal else 0) | native.STEP_COUNT_RAW | native.STEP_COUNT_JUMPS
             hf = float(np.float32(h))
             for i in range(nst):
                 t_ones = torch.full((N,), float(t32[i]), device=dev)
@@ -274,16 +280,19 @@ class MidPointTauL(_GridSampler):
                                                       self.eps_ratio, h)
                 logits_p = model(x_prime.long(), t_05).float().contiguous()
                 x_new = self._leap(model, logits_p, x, q_half[i] if need_q else None, fast_half, i, b_half[i], hf,
-                                   flags, key, i, x_base=x_prime, changed=cnt[1, i:i + 1])
-                cnt[0, i] = (x != x_prime).sum()
-                cnt[2, i] = (x_prime != x_new).sum()
+                                   flags, key, i, x_base=x_prime, changed=cnt[i, 0:3])
+                cnt[i, 3] = (x != x_prime).sum()
+                cnt[i, 4] = (x_prime != x_new).sum()
                 x = x_new
             if self.loss_name == "CTElbo":
                 x = self._final_argmax(model, x, N)
-            c = cnt.cpu().numpy().astype(np.float64) / (N * self.D)
-            # (samples, change_jump, change_dim, change_dim_first, change_1to2); the multi-jump
-            # proportion `change_jump` needs per-element counts the fused draw never forms.
-            return x.cpu().numpy().astype(int), [], c[1].tolist(), c[0].tolist(), c[2].tolist()
+            raw = cnt.cpu().numpy().astype(np.float64)
+            c = raw / (N * self.D)
+            # (samples, change_jump, change_dim, change_dim_first, change_1to2); change_jump = share of the jumping
+            # dimensions that drew more than one event, appended only when is_ordinal (sampling.py:489-495; 0/0 -> nan there too)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                change_jump = (raw[:, 2] / raw[:, 1]).tolist() if self.is_ordinal else []
+            return x.cpu().numpy().astype(int), change_jump, c[:, 0].tolist(), c[:, 3].tolist(), c[:, 4].tolist()
 
 
 @sampling_utils.register_sampler
@@ -299,7 +308,7 @@ class PCTauL(_GridSampler):
         s = self.cfg.sampler
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad():
+        with torch.no_grad(), borrow_engine_output(model):
             x = self._initial(model, N, key, 200)
             h0 = 1.0 / s.num_steps
             ts = np.linspace(1.0, s.min_t + h0, s.num_steps)
@@ -341,7 +350,7 @@ class ExactSampling(_GridSampler):
     def sample(self, model, N):
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad():
+        with torch.no_grad(), borrow_engine_output(model):
             x = self._initial(model, N, key, self.cfg.model.Q_sigma).long()
             ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
             pr = model.process
@@ -364,20 +373,33 @@ class ExactSampling(_GridSampler):
             return x.cpu().numpy().astype(int), change.cpu().tolist()
 
 
-def lbjf_corrector_step(cfg, model, xt, t, h, N, device, xt_target=None):
+def lbjf_corrector_step(cfg, model, xt, t, h, N, device, xt_target=None, seed=None, E=None, want_probs=False):
     """One Euler corrector step with SDDM ratios (sampling.py:1064-1085):
-    posterior = h * (exp(ll_all - ll_xt) + 1) * R_t[x_t, :] off the diagonal, clip(1 - sum, 0) on it."""
-    if xt_target is None:
-        xt_target = xt
-    t_ones = t * torch.ones((N,), device=device) if not torch.is_tensor(t) else t
-    logits = model(xt, t_ones)
-    ll_all, ll_xt = get_logprob_with_logits(cfg=cfg, model=model, xt=xt, t=t_ones, logits=logits)
-    fwd = model.rate_mat(xt.long(), t_ones)
-    own = torch.nn.functional.one_hot(xt_target.long(), cfg.data.S).to(fwd.dtype)
-    post = h * (torch.exp(ll_all - ll_xt.unsqueeze(-1)) * fwd + fwd) * (1 - own)
-    post = post + torch.clip(1.0 - post.sum(-1, keepdim=True), min=0) * own
-    post = post / post.sum(-1, keepdim=True)
-    return torch.distributions.categorical.Categorical(logits=torch.log(post + 1e-35)).sample()
+    posterior = h * (exp(ll_all - ll_xt) + 1) * R_t[x_t, :] off the diagonal, clip(1 - sum, 0) on it, normalised, then one
+    categorical draw per dimension.  That is the Euler posterior of the corrector rates R^ + R_t[x_t, :], i.e. ONE
+    `ctdd_lbjf_step` launch with CTDD_STEP_CORRECTOR on the CRM branch (K5 + K7 fused).
+    The reference body only runs when D == S (it multiplies the (N,D,S) ratios by the (N,S,S) `model.rate(t)` and so
+    takes the rate row of the DIMENSION index, and it passes log-probabilities to Categorical as `probs`); nothing calls
+    it.  This is the formula its docstring and the LBJF corrector (sampling.py:296-341) state: rate row of the STATE
+    x_t, Categorical(logits=log posterior).  Parity: oracle restatement `oracle.samplers.lbjf_corrector_posterior`
+    (reference fixture impossible: parity unpinned)."""
+    if torch.is_tensor(t):
+        t = float(t.reshape(-1)[0])
+    t32 = torch.tensor([t], dtype=torch.float64).to(torch.float32)
+    t_ones = torch.full((N,), float(t32[0]), device=device, dtype=torch.float32)
+    with torch.no_grad():
+        logits = model(xt.long(), t_ones).float().contiguous()
+    lt = getattr(cfg.loss, "logit_type", "direct")
+    pr = model.process
+    q = pr.tables(t32, want_qt0=True)[0][0] if lt != "direct" else None
+    beta = float(pr.beta(t32)[0])
+    if xt_target is not None and xt_target is not xt and not torch.equal(xt_target, xt):
+        raise NotImplementedError("lbjf_corrector_step: xt_target != xt (own-state mask of another state) is not built; "
+                                  "no reference caller uses it")
+    out = native.lbjf_step(native.BRANCH_CRM, lt, logits, xt.to(torch.int32).contiguous(), q, pr.base_rate, beta,
+                           cfg.sampler.eps_ratio, float(h), native.STEP_CORRECTOR, E, seed if seed is not None else _fresh_seed(), 0,
+                           want_probs=want_probs)
+    return (out[0].long(), out[1]) if want_probs else out.long()
 
 
 # Names that shipped configs still use but the reference never registers (SURVEY 0.2): resolve

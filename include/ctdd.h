@@ -46,6 +46,8 @@ extern "C" {
 #define CTDD_STEP_ORDINAL 1u     /* cfg.sampler.is_ordinal (sampling.py:135-138)                 */
 #define CTDD_STEP_CORRECTOR 2u   /* add rate[x][s] to R^ (corrector, sampling.py:182-198)        */
 #define CTDD_STEP_COUNT_RAW 4u   /* out_changed counts the UNCLIPPED move != 0 (sampling.py:505) */
+#define CTDD_STEP_COUNT_JUMPS 16u /* out_changed is int32[3]: [1] += #dims with >= 1 jump event, [2] += #dims with > 1
+                                    (MidPointTauL's change_jump = [2]/[1], sampling.py:489-495) */
 #define CTDD_STEP_CRM 8u         /* ctdd_tauleap_step_s256 only: CRM-branch rates with logit_type reverse_prob (sampling.py:61-73);
                                   * the step tables must come from ctdd_s256_prepare_crm */
 
@@ -216,6 +218,13 @@ int ctdd_opt_chunk_elems(void);
 int ctdd_adam_ema_step(const void* tensors, const void* chunks, int nchunks, float lr, float beta1, float beta2,
                        float eps, int64_t step, float max_norm, float ema_decay, double* sumsq_scratch,
                        void* stream);
+/* The two launches on their own, for parameters that fall into several tables (param groups with different
+ * hyper-parameters; tensors whose Adam step counts differ -- torch.optim.Adam keeps `step` per parameter): the
+ * squared gradient norm of every table summed into ONE scalar (clip_grad_norm_ over model.parameters(),
+ * training.py:28-29), then one update per table with its own step / lr. */
+int ctdd_grad_sumsq(const void* tensors, const void* chunks, int nchunks, double* sumsq_scratch, int zero_first, void* stream);
+int ctdd_adam_ema_apply(const void* tensors, const void* chunks, int nchunks, float lr, float beta1, float beta2,
+                        float eps, int64_t step, float max_norm, float ema_decay, const double* sumsq, void* stream);
 
 #ifdef __cplusplus
 }

@@ -193,3 +193,17 @@ def exact_sample(model, N, D, S, *, max_t, min_t, num_steps, initial_dist, init_
         change.append((torch.sum(x_new != x) / (N * D)).item())
         x = x_new
     return x.numpy().astype(int), change
+
+
+def lbjf_corrector_posterior(model, logits, xt, t_ones, h, logit_type):
+    """lbjf_corrector_step (sampling.py:1064-1085) as its docstring and the LBJF corrector (296-341) state it:
+    posterior = h * (exp(ll_all - ll_xt) + 1) * R_t[x_t, :] off the own state, clip(1 - sum, 0) on it, normalised.
+    (The reference body multiplies the (N,D,S) ratio by the (N,S,S) `model.rate(t)`: it only runs for D == S and then
+    takes the rate row of the dimension index; nothing in the reference calls it.)  Returns (N, D, S) probabilities."""
+    qt0 = None if logit_type == "direct" else model.transition(t_ones)
+    ll_all, ll_xt = ops.logprob_with_logits(logit_type, logits, xt, qt0)
+    fwd = model.rate_mat(xt.long(), t_ones)
+    own = F.one_hot(xt.long(), logits.shape[-1]).to(fwd.dtype)
+    post = h * (torch.exp(ll_all - ll_xt.unsqueeze(-1)) * fwd + fwd) * (1 - own)
+    post = post + torch.clip(1.0 - post.sum(-1, keepdim=True), min=0) * own
+    return post / post.sum(-1, keepdim=True)

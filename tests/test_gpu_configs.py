@@ -100,3 +100,68 @@ def test_mnist_unet_ctelbo_train_step():
     model = mu.create_model(cfg, torch.device("cuda"))
     mb = torch.randint(0, 256, (2, 1, 28, 28), device="cuda")
     _one_step(cfg, model, mb)
+
+
+@pytest.mark.parametrize("sampler", ["MidPointTauL", "TauL_corrector"])
+def test_maze_hollow_full_size_samplers(sampler):
+    """BASELINE config (4) at its real size: config_hollow_maze (D = 225, S = 3, 7.8 M-parameter hollow transformer) with
+    MidPointTauL, and with TauL + corrector steps.  The oracle covers these loops at D = 15 (test_gpu_samplers); here the
+    properties that do not depend on the size: shapes, state range, per-step counters consistent with each other, the
+    corrector entered, reproducibility under a fixed Philox key, and the engine (not torch ops) behind model(x, t)."""
+    mu, su, _, _, _ = _registries()
+    from config.maze_config.config_hollow_maze import get_config
+    cfg = get_config()
+    cfg.device = "cuda"
+    cfg.sampler.num_steps = 6
+    if sampler == "MidPointTauL":
+        cfg.sampler.name, cfg.sampler.is_ordinal = "MidPointTauL", True
+    else:
+        cfg.sampler.name = "TauL"
+        cfg.sampler.corrector_entry_time, cfg.sampler.num_corrector_steps = 0.5, 2
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    N, D, S = 64, 225, 3
+    smp = su.get_sampler(cfg)
+    smp.seed = 99
+    out = smp.sample(model, N)
+    assert model._engine is not None and model._engine._plans            # the HIP engine ran the network
+    x = out[0]
+    assert x.shape == (N, D) and x.min() >= 0 and x.max() < S
+    if sampler == "MidPointTauL":
+        assert len(out) == 5
+        change_jump, change_dim, change_first, change_1to2 = (np.asarray(o) for o in out[1:])
+        nst = len(change_dim)
+        assert nst >= 5 and change_jump.shape == change_first.shape == change_1to2.shape == (nst,)
+        assert ((change_dim >= 0) & (change_dim <= 1)).all() and ((change_first >= 0) & (change_first <= 1)).all()
+        fin = np.isfinite(change_jump)
+        assert ((change_jump[fin] >= 0) & (change_jump[fin] <= 1)).all()
+        assert change_dim.max() > 0                                       # the chain moves
+    else:
+        assert len(out) == 2 and len(out[1]) == cfg.sampler.num_steps and max(out[1]) > 0
+    smp2 = su.get_sampler(cfg)
+    smp2.seed = 99
+    assert np.array_equal(smp2.sample(model, N)[0], x)                    # same key, same draws
+    model.train()
+
+
+def test_cifar10_unet_ctelbo_lambda_train_step():
+    """BASELINE config (5): config_tauUnet_cifar10 (CTElboLambda, logistic head, D = 3072): one training step at the
+    configuration's size (K11 sees 3072 rows of 256 states per sample; clip + Adam + EMA in K28)."""
+    mu, _, _, _, _ = _registries()
+    from config.cifar10_config.config_tauUnet_cifar10 import get_config
+    cfg = get_config()
+    assert cfg.loss.name == "CTElboLambda"
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    with torch.no_grad():
+        for name, p in model.named_parameters():                 # the reference zero-scales some convs at init: re-draw
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") / (p[0].numel() ** 0.5))
+    model.init_ema()
+    mb = torch.randint(0, 256, (2, 3, 32, 32), device="cuda")
+    mu_, _, lu, tu, ou = _registries()
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": cfg.training.n_iters // 2}
+    out = tu.get_train_step(cfg).step(state, lu.get_loss(cfg), mb)
+    assert out.dim() == 0 and torch.isfinite(out) and float(out) < 1e8 and model.num_updates == 1

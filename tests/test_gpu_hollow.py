@@ -77,6 +77,35 @@ def test_hollow_engine_matches_module_maze():
     model.train()
 
 
+def test_hollow_engine_matches_module_mnist():
+    """config_hollow_mnist (D=784, S=256, E=256, 9 layers per direction, 14.1 M parameters), batch 2: the three engine
+    precisions against the fp32 module on torch device ops."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from config.mnist_config.config_hollow_mnist import get_config
+    from ctdd.hollow_engine import HollowEngine
+    cfg = get_config()
+    cfg.device = "cuda"
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    assert 14.0e6 < sum(p.numel() for p in model.parameters()) < 14.2e6          # SURVEY App. B: 14.08 M
+    model.eval()
+    x = torch.randint(0, 256, (2, 784), device="cuda")
+    t = torch.tensor([0.05, 0.9], device="cuda")
+    with torch.no_grad():
+        cfg.model.engine = "torch"
+        ref = model(x, t).cpu()
+        out = HollowEngine(model, precision="fp32")(x, t).cpu()
+        split = HollowEngine(model, precision="bf16x3")(x, t).cpu()
+        fast = HollowEngine(model, precision="bf16")(x, t).cpu()
+    scale = max(ref.abs().max().item(), 1.0)
+    assert ref.shape == out.shape == (2, 784, 256)
+    assert (out - ref).abs().max().item() < 1e-4 * scale
+    assert (split - ref).abs().max().item() < 1e-4 * scale
+    assert (fast - ref).abs().max().item() < 5e-2 * scale
+    model.train()
+
+
 @pytest.mark.parametrize("hd", [16, 32])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_attention_kernels_against_masked_softmax(hd, mode):

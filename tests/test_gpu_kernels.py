@@ -40,7 +40,8 @@ def univar(S, tf="sqrt_cos"):
 
 def make_process(kind, S, tf="sqrt_cos"):
     return {"gaussian": lambda: gauss(S), "univar": lambda: univar(S, tf),
-            "uniform": lambda: ForwardProcess("uniform", S, rate_const=1.7)}[kind]()
+            "uniform": lambda: ForwardProcess("uniform", S, rate_const=1.7),
+            "birthdeath": lambda: ForwardProcess("birthdeath", S, sigma_min=1.0, sigma_max=100.0)}[kind]()
 
 
 def tables(nat, proc, t, **want):
@@ -62,7 +63,7 @@ def test_philox_bit_exact(nat):
 
 # ------------------------------------------------------------------ K1
 @pytest.mark.parametrize("kind,S", [("gaussian", 256), ("gaussian", 8), ("gaussian", 100), ("univar", 3),
-                                    ("univar", 2), ("uniform", 3)])
+                                    ("univar", 2), ("uniform", 3), ("birthdeath", 8), ("birthdeath", 32)])
 def test_rate_table(nat, kind, S):
     proc = make_process(kind, S)
     t = torch.tensor([0.01, 0.25, 0.5, 0.75, 0.99999])

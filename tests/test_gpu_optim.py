@@ -102,3 +102,30 @@ def test_train_step_uses_fused_update_on_gpu():
         torch.testing.assert_close(b, a, rtol=5e-5, atol=1e-7)
     for a, b in zip(ref.shadow_params, model.shadow_params):
         torch.testing.assert_close(b, a, rtol=5e-5, atol=1e-7)
+
+
+def test_fused_adam_mixed_step_counts_and_param_groups():
+    """torch.optim.Adam keeps `step` per parameter and clip_grad_norm_ takes ONE norm over all parameters: a parameter
+    that gets its first gradient later (a sub-module that becomes used, a tensor unfrozen mid-run) and a second param
+    group with another learning rate must still follow the torch sequence."""
+    from lib.optimizers.optimizers import FusedAdam
+    shapes = [(64, 33), (129,), (20000,), (7, 9)]
+    pa, pb = _make(3, shapes), _make(3, shapes)
+    groups = lambda ps: [{"params": ps[:2]}, {"params": ps[2:], "lr": 5e-4}]
+    ref_opt = torch.optim.Adam(groups(pa), 2e-3)
+    opt = FusedAdam(groups(pb), 2e-3)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for it in range(5):
+        grads = [torch.randn(s, generator=g, device="cuda") * 0.3 for s in shapes]
+        for plist in (pa, pb):
+            for i, (p, gr) in enumerate(zip(plist, grads)):
+                late = i in (1, 3) and it < 2                                   # these two see their first gradient at it = 2
+                p.grad = None if late else gr.clone()
+        torch.nn.utils.clip_grad_norm_(pa, 0.5)
+        ref_opt.step()
+        opt.fused_step(0.5, None, -1.0, pb)
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(b, a, rtol=3e-5, atol=1e-7)
+    sa, sb = ref_opt.state_dict()["state"], opt.state_dict()["state"]
+    assert [float(sb[k]["step"]) for k in sorted(sb)] == [float(sa[k]["step"]) for k in sorted(sa)] == [5.0, 3.0, 5.0, 3.0]

@@ -64,7 +64,7 @@ def _two_sample_chi2(a, b, S):
 
 
 @pytest.mark.parametrize("case", ["taul_ord", "taul_nonord", "taul_corr", "taul_crm", "lbjf", "lbjf_crm_corr",
-                                  "midpoint", "pctaul", "exact"])
+                                  "midpoint", "midpoint_ord", "pctaul", "exact"])
 def test_sampler_distribution_matches_oracle(case):
     import lib.sampling.sampling  # noqa: F401
     import lib.sampling.sampling_utils as su
@@ -77,6 +77,7 @@ def test_sampler_distribution_matches_oracle(case):
         "lbjf": ("LBJF", "gaussian", 16, 10, "CTElbo", "direct", dict(), 1.0),
         "lbjf_crm_corr": ("LBJF", "univar", 3, 15, "CatRMNLL", "reverse_logscale", dict(initial_dist="uniform", max_t=0.99999, corrector_entry_time=0.5, num_corrector_steps=1), 3.0),
         "midpoint": ("MidPointTauL", "univar", 3, 15, "CatRM", "reverse_prob", dict(is_ordinal=False, initial_dist="uniform", max_t=0.99999), 3.0),
+        "midpoint_ord": ("MidPointTauL", "gaussian", 16, 10, "CTElbo", "direct", dict(is_ordinal=True), 6.0),
         "pctaul": ("PCTauL", "gaussian", 16, 10, "CTElbo", "direct", dict(corrector_entry_time=0.7, num_corrector_steps=2, initial_dist="gaussian"), 1.0),
         "exact": ("ExactSampling", "univar", 3, 15, "CatRM", "direct", dict(initial_dist="uniform", max_t=0.99999), 3.0),
     }[case]
@@ -132,6 +133,40 @@ def test_sampler_distribution_matches_oracle(case):
         assert len(out) == 5 and len(out[2]) == len(ref[2])
         assert np.abs(np.asarray(out[3]) - np.asarray(ref[3])).max() < 0.03      # deterministic predictor stage
         assert np.abs(np.asarray(out[2]) - np.asarray(ref[2])).max() < 0.03
+        if s.is_ordinal:         # change_jump (sampling.py:489-495): share of jumping dimensions with more than one event
+            cj, cj_ref = np.asarray(out[1]), np.asarray(ref[1])
+            assert cj.shape == cj_ref.shape == (len(ref[2]),)
+            ok = np.isfinite(cj) & np.isfinite(cj_ref)
+            assert ok.sum() >= len(cj) - 2 and np.abs(cj[ok] - cj_ref[ok]).max() < 0.05, (cj, cj_ref)
+            assert cj_ref[ok].max() > 0.02          # the case does exercise multi-jump dimensions
+        else:
+            assert out[1] == []
+
+
+@pytest.mark.parametrize("kind,S,lt", [("univar", 3, "reverse_prob"), ("univar", 3, "direct"), ("gaussian", 16, "reverse_logscale")])
+def test_lbjf_corrector_step(kind, S, lt):
+    """lib.sampling.sampling.lbjf_corrector_step (reference sampling.py:1064-1085) = one ctdd_lbjf_step launch with the
+    corrector flag on the CRM branch: posterior rows against the oracle restatement, draws exact given the same
+    exponential noise (up to float near-ties), and a Philox run with the right change rate."""
+    import lib.sampling.sampling as ls
+    from oracle import ctmc_ops as ops
+    N, D, h, t = 64, 15, 0.02, 0.4
+    params = GAUSS if kind == "gaussian" else dict(rate_const=1.7, t_func="sqrt_cos")
+    cfg = _cfg(S, D, "LBJF", "CatRM", lt, **(dict(rate_const=1.7, t_func="sqrt_cos") if kind == "univar" else {}))
+    model = DeviceToy(kind, S, 3.0, **params)
+    g = torch.Generator().manual_seed(3)
+    xt = torch.randint(0, S, (N, D), generator=g)
+    E = torch.empty(N * D, S).exponential_(1, generator=g)
+    new_y, probs = ls.lbjf_corrector_step(cfg, model, xt.cuda(), t, h, N, "cuda", E=E.cuda(), want_probs=True)
+    om = ToyModel(ForwardProcess(kind, S, **params), S, scale=3.0)
+    t_ones = torch.full((N,), float(np.float32(t)))
+    post = osamp.lbjf_corrector_posterior(om, om(xt, t_ones), xt, t_ones, h, lt)
+    np.testing.assert_allclose(probs.cpu().numpy(), post.numpy(), rtol=3e-4, atol=1e-9)
+    ref = ops.exp_race_argmax(ops.categorical_probs_from_logits(torch.log(post + 1e-35).view(-1, S)), E).view(N, D)
+    assert new_y.dtype == torch.int64 and (new_y.cpu() != ref).float().mean().item() < 2e-3
+    y2 = ls.lbjf_corrector_step(cfg, model, xt.cuda(), t, h, N, "cuda", seed=11)
+    stay = post.gather(-1, xt.unsqueeze(-1)).mean().item()
+    assert abs((y2.cpu() == xt).float().mean().item() - stay) < 4 * np.sqrt(stay * (1 - stay) / (N * D)) + 0.01
 
 
 def test_unet_model_samples_end_to_end():

@@ -92,6 +92,118 @@ def test_engine_matches_module_mnist():
     model.train()
 
 
+def _mnist_model(seed=0, **model_over):
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.model.update(model_over)
+    torch.manual_seed(seed)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(seed + 1)
+    with torch.no_grad():                           # (the reference zero-initialises the output conv: re-draw so logits vary)
+        for name, p in model.named_parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g, device="cuda") / (p[0].numel() ** 0.5))
+    model.init_ema()
+    return cfg, model
+
+
+def test_eval_forwards_do_not_alias():
+    """Two eval/no_grad forwards of the same batch size return distinct tensors (the engine's plan owns ONE output buffer;
+    the wrapper hands out copies unless a sampler loop borrows it), and the two-forward-pass CT-ELBO in eval mode
+    (x_logits = model(x_t), then logits at x~) equals the torch-op model's value."""
+    import lib.losses.losses  # noqa: F401
+    import lib.losses.losses_utils as lu
+    from lib.models.models import borrow_engine_output
+    cfg, model = _mnist_model()
+    model.eval()
+    xa = torch.randint(0, 256, (4, 784), device="cuda")
+    xb = torch.randint(0, 256, (4, 784), device="cuda")
+    t = torch.tensor([0.1, 0.4, 0.7, 0.95], device="cuda")
+    with torch.no_grad():
+        a = model(xa, t)
+        a0 = a.clone()
+        b = model(xb, t)
+        assert a.data_ptr() != b.data_ptr() and torch.equal(a, a0) and not torch.equal(a, b)
+        with borrow_engine_output(model):           # the sampler loops: zero-copy, next forward overwrites
+            c = model(xa, t)
+            d = model(xb, t)
+            assert c.data_ptr() == d.data_ptr()
+        assert not getattr(model, "_borrow_engine_output", False)
+        cfg.loss.one_forward_pass = False
+        loss = lu.get_loss(cfg)
+        state = {"model": model, "n_iter": 0}
+        mb = torch.randint(0, 256, (4, 1, 28, 28), device="cuda")
+        torch.manual_seed(5)
+        l_eng = loss.calc_loss(state, mb, None).item()
+        cfg.model.engine = "torch"
+        torch.manual_seed(5)
+        l_ref = loss.calc_loss(state, mb, None).item()
+        cfg.model.engine = "hip"
+    assert np.isfinite(l_ref) and abs(l_eng - l_ref) < 2e-2 * abs(l_ref) + 1e-3, (l_eng, l_ref)     # bf16 engine vs fp32 ops
+    model.train()
+
+
+def test_engine_sub_batch_streams_match_single_plan():
+    """The headline path: a batch replayed as two HIP-graph sub-batches on parallel streams into slices of one logits
+    buffer (engine_streams = 2) against one full-batch plan (engine_streams = 1), over consecutive calls with new inputs."""
+    from ctdd.unet_engine import UNetEngine
+    cfg, model = _mnist_model(seed=3)
+    model.eval()
+    B = 64
+    with torch.no_grad():
+        cfg.model.engine_streams = 2
+        e2 = UNetEngine(model, precision="bf16")
+        cfg.model.engine_streams = 1
+        e1 = UNetEngine(model, precision="bf16")
+        for it in range(4):
+            x = torch.randint(0, 256, (B, 1, 28, 28), device="cuda")
+            t = torch.rand(B, device="cuda") * 0.98 + 0.01
+            cfg.model.engine_streams = 2
+            o2 = e2(x, t).clone()
+            cfg.model.engine_streams = 1
+            o1 = e1(x, t).clone()
+            assert any(len(k) == 3 for k in e2._plans) and all(len(k) == 2 for k in e1._plans)
+            assert torch.equal(o1, o2), (it, (o1 - o2).abs().max().item())      # same kernels per sample: bit-identical
+    cfg.model.engine_streams = 2
+    model.train()
+
+
+def test_engine_behind_ddp_wrapper():
+    """cfg.distributed wraps the network in DistributedDataParallel (models.py:104-107); eval-mode sampling still runs the
+    HIP engine on the module behind the wrapper."""
+    import os
+    import torch.distributed as dist
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        cfg = get_config()
+        cfg.distributed = True
+        torch.manual_seed(0)
+        model = mu.create_model(cfg, torch.device("cuda"), rank=0)
+        assert model.net.__class__.__name__ == "DistributedDataParallel"
+        model.eval()
+        x = torch.randint(0, 256, (2, 784), device="cuda")
+        t = torch.tensor([0.2, 0.8], device="cuda")
+        with torch.no_grad():
+            out = model(x, t)
+            assert model._engine is not None and model._engine._plans
+            cfg.model.engine = "torch"
+            ref = model(x, t)
+        assert (out - ref).abs().max().item() < 5e-2 * max(ref.abs().max().item(), 1e-3) + 1e-4
+        model.train()
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def _conv_case(B, H, W, segs, N, ksplit, seed):
     """Random NHWC bf16 segments + [N][K] weights; returns (args builder inputs, fp32 torch reference)."""
     import torch.nn.functional as F
