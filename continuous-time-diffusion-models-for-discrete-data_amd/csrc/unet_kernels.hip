@@ -35,7 +35,7 @@ __device__ inline unsigned pack2_bf16(float a, float b) {
 __device__ inline unsigned short to_bf16(float a) { return (unsigned short)(pack2_bf16(a, 0.0f) & 0xFFFFu); }
 __device__ inline float from_bf16(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-enum SegKind { SEG_3x3 = 0, SEG_1x1 = 1, SEG_3x3_S2 = 2, SEG_3x3_UP = 3 };
+enum SegKind { SEG_3x3 = 0, SEG_1x1 = 1, SEG_3x3_S2 = 2, SEG_3x3_UP = 3, SEG_3x3_S2T = 4 };
 
 struct ConvSeg {
   const unsigned short* hi;   // [B][Hin][Win][C] bf16   (bf16 mode)
@@ -461,8 +461,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
       if (kind == SEG_3x3) { yy = py[i] + dy - 1; xx = px[i] + dx - 1; }
       else if (kind == SEG_1x1) { yy = py[i]; xx = px[i]; }
       else if (kind == SEG_3x3_S2) { yy = 2 * py[i] + dy; xx = 2 * px[i] + dx; }       // pad right/bottom only
+      else if (kind == SEG_3x3_S2T) { yy = py[i] - dy; xx = px[i] - dx; }              // transpose of the stride-2 conv: 2 oy + dy = y
       else { yy = py[i] + dy - 1; xx = px[i] + dx - 1; }                               // on the upsampled grid
-      if (kind == SEG_3x3_UP) {
+      if (kind == SEG_3x3_S2T) {
+        ok = ok && yy >= 0 && xx >= 0 && !((yy | xx) & 1);
+        yy >>= 1; xx >>= 1;
+        ok = ok && yy < a.Hin && xx < a.Win;
+      } else if (kind == SEG_3x3_UP) {
         ok = ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
         yy >>= 1; xx >>= 1;
       } else if (kind == SEG_3x3_S2 || kind == SEG_3x3) {

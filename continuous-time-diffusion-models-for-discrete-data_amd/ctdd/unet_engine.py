@@ -90,8 +90,12 @@ def supports(model):
 
 
 def training_supported(model):
-    """Whether the hand-written training plan (forward that keeps what backward needs + HIP backward) covers this model."""
-    return False
+    """Whether the hand-written training plan (forward that keeps what backward needs + HIP backward) covers this model:
+    the same U-Nets as the inference engine with channel counts in multiples of 16."""
+    if getattr(model.cfg.model, "engine_train", "hip") != "hip" or not supports(model):
+        return False
+    net = _unwrap(model.net)
+    return net.channel % 16 == 0 and all((net.channel * int(m_)) % 16 == 0 for m_ in model.cfg.model.ch_mult)
 
 
 class _Tensor:
@@ -133,6 +137,19 @@ class UNetEngine:
         return (None, w) if self.precise else (w.to(torch.bfloat16).contiguous(), None)
 
     @staticmethod
+    def _w2d(wsrc, segs):
+        """The [N][K] matrix of a convolution, K = segment -> tap -> channel, from per-segment (parameter, channel offset)."""
+        parts = []
+        for (w, c_off), (_, cs, kind) in zip(wsrc, segs):
+            w = w.detach().float()
+            N = w.shape[0]
+            if kind == SEG_1x1:
+                parts.append(w.reshape(N, -1)[:, c_off:c_off + cs])
+            else:
+                parts.append(w[:, c_off:c_off + cs].permute(0, 2, 3, 1).reshape(N, 9 * cs))
+        return torch.cat(parts, dim=1).contiguous()
+
+    @staticmethod
     def _conv_w(weight, splits):
         """torch conv weight [N][Cin][3][3] -> [N][K], K = segment -> tap -> channel."""
         parts, c0 = [], 0
@@ -147,7 +164,7 @@ class UNetEngine:
         self._stats_off += n
         return off
 
-    def _build(self, B, x_dtype, logits_out=None):
+    def _build(self, B, x_dtype, logits_out=None, tc=None):
         net, m = self.net, self.cfg.model
         lib = _lib()
         dev = self.dev
@@ -172,7 +189,7 @@ class UNetEngine:
                     raise native.CtddError(f"{fn.__name__} failed ({rc}): {lib.ctdd_last_error().decode()}")
             run.label = (fn.__name__, label)
             run.flops = flops                      # matrix FLOPs of the launch (bench.py's network roofline)
-            plan.append(run)
+            cur_lists["plan"].append(run)
 
         bks = (32, 16) if self.precise else (96, 64, 32, 16)      # fp32 tiles: K = 32 keeps 4 workgroups per CU
 
@@ -195,17 +212,30 @@ class UNetEngine:
 
         stats_views = []          # (tensor, offset) resolved after the pool exists
         zero_views = []           # split-K partial-sum buffers: (conv args, elements)
+        cur_lists = {"plan": plan, "zero": zero_views}     # the training context points these at the backward plan
 
-        def conv(segs, w2d, bias, N, Hout, Wout, Hin, Win, out, tb=None, res=None, logits_C=0, out_f32_tensor=None):
-            """segs: list of (_Tensor, channels, kind)."""
+        def conv(segs, wsrc, bias, N, Hout, Wout, Hin, Win, out, tb=None, res=None, logits_C=0, out_f32_tensor=None, bias_params=None,
+                 packed=None, back=True):
+            """segs: list of (_Tensor, channels, kind); wsrc: per segment (weight parameter [N][Cin_tot][k][k], channel offset) --
+            the [N][K] matrix the kernels stream is K = segment -> tap -> channel of those slices.  bias_params: the
+            parameters whose sum `bias` is (training: each receives the bias gradient).  packed: (bf16 | None, fp32 | None)
+            ready-made weights (the data-gradient convolutions of the training plan)."""
             a = _ConvArgs()
             a.nseg = len(segs)
             for i, (src, cs, kind) in enumerate(segs):
                 a.seg[i].hi, a.seg[i].f32, a.seg[i].C, a.seg[i].kind = ptr(src.hi), ptr(src.f32), cs, kind
-            whi, wf = self._pack(w2d)
+            Ktot = sum(cs * (1 if kind == SEG_1x1 else 9) for _, cs, kind in segs)
+            if packed is not None:
+                whi, wf = packed
+            elif tc is not None:
+                whi, wf = tc.packed_forward(wsrc, segs, N, Ktot)     # persistent buffers, refreshed by ONE pack launch per step
+            else:
+                w2d = self._w2d(wsrc, segs)
+                assert w2d.shape[1] == Ktot
+                whi, wf = self._pack(w2d)
             keep.extend([whi, wf, bias])
             a.w_hi, a.w_f32 = ptr(whi), ptr(wf)
-            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = B, Hout, Wout, Hin, Win, N, w2d.shape[1]
+            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = B, Hout, Wout, Hin, Win, N, Ktot
             a.bias = ptr(bias)
             if tb is not None:
                 a.tbias, a.tb_stride = tb
@@ -227,7 +257,9 @@ class UNetEngine:
             hw_ = Hout * Wout
             patchable = patchable and N % 8 == 0 and (hw_ >= 32 or hw_ == 16 or B == 1) and (logits_C == 0 or (N // logits_C) % 8 == 0)
             M_ = B * Hout * Wout
-            lab = f"{Hout}x{Wout} K={w2d.shape[1]} N={N} segs={[(c_, k_) for _, c_, k_ in segs]}"
+            lab = f"{Hout}x{Wout} K={Ktot} N={N} segs={[(c_, k_) for _, c_, k_ in segs]}"
+            if tc is not None and back:
+                tc.record_conv(conv, segs, wsrc, bias_params, N, Hout, Wout, Hin, Win, out, tb, res, logits_C, out_f32_tensor)
             which = getattr(m, "conv_kernel", "auto")
             only3 = all(s[2] == SEG_3x3 for s in segs)
             if which == "auto":
@@ -250,9 +282,9 @@ class UNetEngine:
                 if getattr(m, "conv_ksplit", 1) > 1 and units >= 2 and logits_C == 0:
                     a.ksplit = min(units, int(m.conv_ksplit))
                 if a.ksplit > 1:
-                    zero_views.append((a, M_ * N))
+                    cur_lists["zero"].append((a, M_ * N))
                 fn = lib.ctdd_unet_conv_res if resident else lib.ctdd_unet_conv_ring
-                launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}", flops=2 * M_ * N * w2d.shape[1])
+                launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}", flops=2 * M_ * N * Ktot)
             elif patchable:
                 # throughput kernel: slab staged once per channel chunk (csrc/unet_kernels.hip: k_conv_patch)
                 small = -(-M_ // 128) * -(-N // 96) < 256            # too few 128 x 96 tiles to fill the chip: 32-column tiles
@@ -276,18 +308,18 @@ class UNetEngine:
                 elif nwg <= int(getattr(m, "ksplit_max_wgs", 96)) and units >= 4 and logits_C == 0 and out_f32_tensor is None:
                     a.ksplit = max(1, min(units // 2, 256 // nwg))       # tiny grids (4x4 levels): split K to fill the chip
                 if a.ksplit > 1:
-                    zero_views.append((a, M_ * N))
+                    cur_lists["zero"].append((a, M_ * N))
                 launch(lib.ctdd_unet_conv_patch, C.byref(a), bk, bnt, wm, label=lab + f" patch bk={bk} bnt={bnt} wm={wm} ks={a.ksplit}",
-                       flops=2 * M_ * N * w2d.shape[1])
+                       flops=2 * M_ * N * Ktot)
             else:
                 bk = pick_bk(cs)
                 bnt = pick_bnt(N, bk)
                 if (not self.precise) and -(-M_ // 128) * -(-N // (32 * bnt)) < 64 and bk in (96, 64, 32):
                     bnt = 1                                        # tiny grids: 32-column tiles, more workgroups
-                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}", flops=2 * M_ * N * w2d.shape[1])
+                launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}", flops=2 * M_ * N * Ktot)
 
-        def gn_apply(srcs, norm, swish, eps, HW):
-            """srcs: one or two _Tensor; returns activated planes tensor."""
+        def gn_apply(srcs, norm, swish, eps, HW, drop_p=0.0):
+            """srcs: one or two _Tensor; returns activated planes tensor (training: dropout applied in place after it)."""
             Ct = sum(s.C for s in srcs)
             out = _Tensor(self, B, srcs[0].H, srcs[0].W, Ct, stats=False)
             a = _GnArgs()
@@ -304,6 +336,8 @@ class UNetEngine:
             a.B, a.HW, a.G, a.eps, a.swish = B, HW, norm.num_groups, eps, int(swish)
             a.out_hi, a.out_f32 = ptr(out.hi), ptr(out.f32)
             launch(lib.ctdd_unet_gn_apply, C.byref(a), label=f"gn {srcs[0].H}x{srcs[0].W} C={Ct} ({len(srcs)} src)")
+            if tc is not None:
+                tc.record_gn(srcs, norm, swish, eps, HW, out, drop_p, launch, stats_views)
             return out
 
         # ---- time embedding + all ResBlock projections in two launches
@@ -321,7 +355,10 @@ class UNetEngine:
         ta.t, ta.B, ta.ch, ta.tdim = ptr(st.t_in), B, ch, tdim
         ta.w1, ta.b1, ta.w2, ta.b2, ta.hid, ta.act = ptr(tw[0]), ptr(tw[1]), ptr(tw[2]), ptr(tw[3]), ptr(st.thid), ptr(st.tact)
         keep.extend(tw + [pw, pb, ta])
-        launch(lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
+        if tc is None:
+            launch(lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
+        else:
+            tc.tproj, tc.resblocks = st.tproj, resblocks          # filled by the caller before the plan runs
         toff = {}
         o = 0
         for rb in resblocks:
@@ -347,6 +384,8 @@ class UNetEngine:
         stats_views.append((fa, cur.stats))
         keep.extend([w0, b0, fa])
         launch(lib.ctdd_unet_first_conv, C.byref(fa))
+        if tc is not None:
+            tc.record_first(c0, fa, cur)
 
         def resblock(rb, srcs):
             """srcs: list of 1-2 tensors forming the (virtual) channel concatenation."""
@@ -356,24 +395,26 @@ class UNetEngine:
             a1 = gn_apply(srcs, rb.norm1, True, rb.norm1.eps, Hc * Wc)
             h = _Tensor(self, B, Hc, Wc, cout)
             b1 = rb.conv1.bias.detach().float().contiguous()
-            conv([(a1, a1.C, SEG_3x3)], self._conv_w(rb.conv1.weight.detach().float(), [a1.C]), b1, cout, Hc, Wc,
-                 Hc, Wc, h, tb=(st.tproj.data_ptr() + 4 * toff[id(rb)], Ntot))
-            a2 = gn_apply([h], rb.norm2, True, rb.norm2.eps, Hc * Wc)
+            conv([(a1, a1.C, SEG_3x3)], [(rb.conv1.weight, 0)], b1, cout, Hc, Wc,
+                 Hc, Wc, h, tb=(st.tproj.data_ptr() + 4 * toff[id(rb)], Ntot), bias_params=[rb.conv1.bias])
+            drop = float(rb.dropout.p) if (tc is not None and tc.dropout) else 0.0
+            a2 = gn_apply([h], rb.norm2, True, rb.norm2.eps, Hc * Wc, drop_p=drop)
             y = _Tensor(self, B, Hc, Wc, cout)
-            w2 = self._conv_w(rb.conv2.weight.detach().float(), [cout])
-            bias2 = rb.conv2.bias.detach().float()
+            wsrc = [(rb.conv2.weight, 0)]
+            bias2, bias_params = rb.conv2.bias.detach().float(), [rb.conv2.bias]
             segs = [(a2, cout, SEG_3x3)]
             res = None
             if rb.skip is not None:
-                sw, c_ = rb.skip.weight.detach().float(), 0
+                c_ = 0
                 for s_ in srcs:                       # linear skip folded in as 1x1 K-segments on the raw input
                     segs.append((s_, s_.C, SEG_1x1))
-                    w2 = torch.cat([w2, sw[:, c_:c_ + s_.C]], dim=1)
+                    wsrc.append((rb.skip.weight, c_))
                     c_ += s_.C
-                bias2 = bias2 + rb.skip.bias.detach().float()
+                bias_params.append(rb.skip.bias)
+                bias2 = tc.summed_bias(bias_params) if tc is not None else bias2 + rb.skip.bias.detach().float()
             else:
                 res = srcs[0]
-            conv(segs, w2.contiguous(), bias2.contiguous(), cout, Hc, Wc, Hc, Wc, y, res=res)
+            conv(segs, wsrc, bias2.contiguous(), cout, Hc, Wc, Hc, Wc, y, res=res, bias_params=bias_params)
             return y
 
         def attention(att, x):
@@ -382,16 +423,21 @@ class UNetEngine:
             Cx = x.C
             qkv = torch.empty((B * T, 3 * Cx), dtype=torch.float32, device=dev)
             keep.append(qkv)
-            conv([(an, Cx, SEG_1x1)], att.qkv.weight.detach().float().reshape(3 * Cx, Cx).contiguous(),
-                 att.qkv.bias.detach().float().contiguous(), 3 * Cx, x.H, x.W, x.H, x.W, None, out_f32_tensor=qkv)
+            if tc is not None:
+                tc.begin_attention(att, x, qkv)
+            conv([(an, Cx, SEG_1x1)], [(att.qkv.weight, 0)],
+                 att.qkv.bias.detach().float().contiguous(), 3 * Cx, x.H, x.W, x.H, x.W, None, out_f32_tensor=qkv,
+                 bias_params=[att.qkv.bias])
             ao = _Tensor(self, B, x.H, x.W, Cx, stats=False)
             aa = _AttnArgs()
             aa.qkv, aa.B, aa.T, aa.C, aa.heads, aa.out_hi, aa.out_f32 = ptr(qkv), B, T, Cx, att.num_heads, ptr(ao.hi), ptr(ao.f32)
             keep.extend([aa, ao])
             launch(lib.ctdd_unet_attention, C.byref(aa))
+            if tc is not None:
+                tc.record_attention(att, qkv, ao, B, T, Cx)
             y = _Tensor(self, B, x.H, x.W, Cx)
-            conv([(ao, Cx, SEG_1x1)], att.proj_out.weight.detach().float().reshape(Cx, Cx).contiguous(),
-                 att.proj_out.bias.detach().float().contiguous(), Cx, x.H, x.W, x.H, x.W, y, res=x)
+            conv([(ao, Cx, SEG_1x1)], [(att.proj_out.weight, 0)],
+                 att.proj_out.bias.detach().float().contiguous(), Cx, x.H, x.W, x.H, x.W, y, res=x, bias_params=[att.proj_out.bias])
             return y
 
         feats = [cur]
@@ -404,8 +450,8 @@ class UNetEngine:
                 cv = layer.downsample[0]
                 Ho, Wo = (cur.H + 1 - 3) // 2 + 1, (cur.W + 1 - 3) // 2 + 1
                 y = _Tensor(self, B, Ho, Wo, cur.C)
-                conv([(cur, cur.C, SEG_3x3_S2)], self._conv_w(cv.weight.detach().float(), [cur.C]),
-                     cv.bias.detach().float().contiguous(), cur.C, Ho, Wo, cur.H, cur.W, y)
+                conv([(cur, cur.C, SEG_3x3_S2)], [(cv.weight, 0)],
+                     cv.bias.detach().float().contiguous(), cur.C, Ho, Wo, cur.H, cur.W, y, bias_params=[cv.bias])
                 cur = y
             feats.append(cur)
         for layer in net.mid:
@@ -420,14 +466,19 @@ class UNetEngine:
             else:                                      # Upsample: nearest x2 folded into the conv's addressing
                 cv = layer[1]
                 y = _Tensor(self, B, cur.H * 2, cur.W * 2, cur.C)
-                if self.precise:
-                    conv([(cur, cur.C, SEG_3x3_UP)], self._conv_w(cv.weight.detach().float(), [cur.C]),
+                if self.precise and tc is None:
+                    conv([(cur, cur.C, SEG_3x3_UP)], [(cv.weight, 0)],
                          cv.bias.detach().float().contiguous(), cur.C, cur.H * 2, cur.W * 2, cur.H, cur.W, y)
-                else:                                  # bf16: materialise the 2x grid (cheap), then the patch kernel
+                else:                                  # materialise the 2x grid (cheap), then a stride-1 convolution (training: both modes)
                     up = _Tensor(self, B, cur.H * 2, cur.W * 2, cur.C, stats=False)
-                    launch(lib.ctdd_unet_upsample2x, ptr(cur.hi), B, cur.H, cur.W, cur.C, ptr(up.hi))
-                    conv([(up, cur.C, SEG_3x3)], self._conv_w(cv.weight.detach().float(), [cur.C]),
-                         cv.bias.detach().float().contiguous(), cur.C, up.H, up.W, up.H, up.W, y)
+                    if self.precise:
+                        launch(lib.ctdd_unet_upsample2x_f32, ptr(cur.f32), B, cur.H, cur.W, cur.C, ptr(up.f32))
+                    else:
+                        launch(lib.ctdd_unet_upsample2x, ptr(cur.hi), B, cur.H, cur.W, cur.C, ptr(up.hi))
+                    if tc is not None:
+                        tc.record_upsample(cur, up)
+                    conv([(up, cur.C, SEG_3x3)], [(cv.weight, 0)],
+                         cv.bias.detach().float().contiguous(), cur.C, up.H, up.W, up.H, up.W, y, bias_params=[cv.bias])
                 cur = y
         ao = gn_apply([cur], net.out[0], True, net.out[0].eps, cur.H * cur.W)
         oc = net.out[2]
@@ -435,21 +486,26 @@ class UNetEngine:
         D = Cin * H0 * W0
         if logistic:
             st.net_out = torch.empty((B * H0 * W0, n_out), dtype=torch.float32, device=dev)
-            conv([(ao, ao.C, SEG_3x3)], self._conv_w(oc.weight.detach().float(), [ao.C]),
-                 oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.net_out)
+            conv([(ao, ao.C, SEG_3x3)], [(oc.weight, 0)],
+                 oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.net_out, bias_params=[oc.bias])
             st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=torch.float32, device=dev)
             la = _LogisticArgs()
             la.net, la.x0, la.B, la.C, la.HW, la.S, la.fix, la.out = (ptr(st.net_out), ptr(st.x0), B, Cin, H0 * W0, S,
                                                                      int(bool(m.fix_logistic)), ptr(st.logits))
             la.fast = 0 if self.precise else 1
             keep.append(la)
-            launch(lib.ctdd_unet_logistic_head, C.byref(la))
+            if tc is None:                             # (training: the head runs as differentiable device ops on net_out)
+                launch(lib.ctdd_unet_logistic_head, C.byref(la))
         else:
             st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=torch.float32, device=dev)
-            conv([(ao, ao.C, SEG_3x3)], self._conv_w(oc.weight.detach().float(), [ao.C]),
+            conv([(ao, ao.C, SEG_3x3)], [(oc.weight, 0)],
                  oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.logits,
-                 logits_C=Cin)
+                 logits_C=Cin, bias_params=[oc.bias])
 
+        if tc is not None:                             # backward plan: built before the pools are laid out
+            st.launch, st.conv, st.stats_views, st.ptr, st.cur_lists, st.keep = launch, conv, stats_views, ptr, cur_lists, keep
+            st.zero_views_fwd = zero_views
+            tc.finish(st, self)
         # ---- the per-(b, channel) statistics pool: one buffer, zeroed once per forward
         st.stats = torch.zeros((max(self._stats_off, 1),), dtype=torch.float64, device=dev)
         base = st.stats.data_ptr()
@@ -557,3 +613,82 @@ class UNetEngine:
         else:
             self._run_plan(st)
         return st.logits
+
+    # ------------------------------------------------------------------ training (ctdd/unet_train.py lays the plans out)
+    def _time_projections(self, times, resblocks):
+        """temb -> every ResBlock's time projection, (B, Ntot): the B x 4ch time MLP stays differentiable device ops."""
+        net = self.net
+        act = torch.nn.functional.silu(net.time(times.float()))
+        w = torch.cat([rb.time[1].weight for rb in resblocks], 0)
+        b = torch.cat([rb.time[1].bias for rb in resblocks], 0)
+        return torch.nn.functional.linear(act, w, b)
+
+    def train_forward(self, x, times):
+        """model(x, t) with gradients: logits (B, D, S) attached to autograd through ONE Function whose backward is the
+        hand-written backward plan."""
+        from . import unet_train
+        unet_train.lib()                                   # (binds the training entry points' signatures)
+        B = x.shape[0]
+        if x.dtype not in (torch.int64, torch.int32):
+            raise native.CtddError(f"UNetEngine expects integer states, got {x.dtype}")
+        dropout = bool(self.model.training) and any(float(getattr(mod, "p", 0.0)) > 0 for mod in self.net.modules()
+                                                    if mod.__class__.__name__ == "Dropout")
+        key = (B, x.dtype, dropout)
+        pool = self.__dict__.setdefault("_train_plans", {}).setdefault(key, [])
+        st = next((p for p in pool if not p.busy), None)
+        if st is None:
+            if len(pool) >= int(getattr(self.cfg.model, "engine_train_plans", 3)):
+                st = min(pool, key=lambda p: p.gen)          # oldest forward never got its backward: reuse, its ctx is invalidated
+            else:
+                tc = unet_train.TrainCtx(self, B, dropout)
+                st = self._build(B, x.dtype, tc=tc)
+                st.gen, st.busy, st.fgraph, st.bgraph, st.warm = 0, False, None, None, 0
+                tc.rng[0] = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+                pool.append(st)
+        tc = st.tc
+        Cin, H0, W0 = self.cfg.data.shape
+        tproj = self._time_projections(times, tc.resblocks)
+        out = unet_train.UNetTrainFn.apply(self, st, x, times, tproj, *tc.engine_params)
+        if self.cfg.model.model_output == "logistic_pars":
+            from lib.models.models import logistic_logits
+            no = out.view(B, H0 * W0, 2 * Cin)
+            loc, log_scale = no[..., :Cin].permute(0, 2, 1), no[..., Cin:].permute(0, 2, 1)          # (B, C, HW)
+            mu = torch.tanh(loc + st.x0.view(B, Cin, H0 * W0))
+            logits = logistic_logits(mu.unsqueeze(-1), log_scale.unsqueeze(-1), self.net.S, bool(self.cfg.model.fix_logistic))
+            return logits.reshape(B, Cin * H0 * W0, self.net.S)
+        return out
+
+    def _train_run_forward(self, st, x, times, tproj):
+        st.gen = self.__dict__["_train_gen"] = self.__dict__.get("_train_gen", 0) + 1
+        st.busy = True
+        st.x_in.copy_(x.reshape(st.x_in.shape))
+        st.t_in.copy_(times.float())
+        st.tc.tproj.copy_(tproj.detach())
+        self._run_plan(st)
+        out = st.net_out if self.cfg.model.model_output == "logistic_pars" else st.logits
+        return out.clone()
+
+    def _train_run_backward(self, st, gen, dout):
+        if gen != st.gen:
+            raise native.CtddError("the training plan of this forward was reused by a later forward before its backward ran "
+                                   "(more concurrent training forwards than cfg.model.engine_train_plans)")
+        tc = st.tc
+        # gradients handed out by the previous backward are views of the arena: a caller that kept them (no zero_grad) gets copies
+        lo, hi = tc.gflat.data_ptr(), tc.gflat.data_ptr() + 4 * tc.gflat.numel()
+        for p in tc.engine_params:
+            if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                p.grad = p.grad.clone()
+        Cin, H0, W0 = self.cfg.data.shape
+        d = dout.detach().float()
+        if self.cfg.model.model_output != "logistic_pars" and Cin > 1:        # (B, C*HW, S) -> NHWC rows [b*HW + p][c*S + s]
+            S = self.net.S
+            d = d.view(-1, Cin, H0 * W0, S).permute(0, 2, 1, 3)
+        tc.seed_in.copy_(d.reshape(tc.seed_in.shape))
+        tc.zbuf.zero_()
+        tc.bzpool.zero_()
+        tc.gflat.zero_()
+        for step in st.bwd_plan:
+            step()
+        st.busy = False
+        grads = [tc.gflat[o:o + n].view(shape) for o, n, shape in (tc.grad_view[id(p)] for p in tc.engine_params)]
+        return tc.dtproj.clone(), grads

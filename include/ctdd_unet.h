@@ -20,6 +20,9 @@ extern "C" {
 #define CTDD_SEG_1x1 1     /* 1x1: ResBlock linear skip / attention qkv, proj        (119-138,165-167)*/
 #define CTDD_SEG_3x3_S2 2  /* 3x3, stride 2, input padded (0,1,0,1)                  (88-97)          */
 #define CTDD_SEG_3x3_UP 3  /* 3x3 pad 1 on the nearest-2x upsampled input            (79-85)          */
+#define CTDD_SEG_3x3_S2T 4 /* transpose of CTDD_SEG_3x3_S2: data gradient of the Downsample conv (backward of 88-97); the
+                              output grid (H, W) is the forward's input grid, (Hin, Win) the forward's output grid;
+                              ctdd_unet_conv (generic kernel) only */
 
 typedef struct { const void* hi; const float* f32; int C, kind; } ctdd_conv_seg;   /* [B][Hin][Win][C] bf16 | fp32 */
 typedef struct {
