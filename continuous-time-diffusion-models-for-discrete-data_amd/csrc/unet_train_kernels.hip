@@ -65,7 +65,9 @@ struct WgradArgs {
   int kind;          // WG_3x3 (stride 1, pad 1) | WG_1x1 | WG_3x3_S2 (stride 2, input padded right/bottom)
   int nlr;           // WG_3x3: extended rows per chunk;  other kinds: pixels per chunk (multiple of 16)
   int nwn;           // waves along n (1, 2 or 4); 4 / nwn along c
-  int nchunks;       // chunks in all; grid.x workgroups share them
+  int nchunks;       // chunks in all; grid_x workgroups share them
+  int grid_x;        // M-split of this entry (<= the launch's grid.x)
+  int tap;           // WG_3x3_S2: the tap this entry computes (nine entries per stride-2 convolution)
 };
 
 // LDS image of a [positions][32 * tiles channels] operand tile.  bf16: the 64-byte pieces (one 32-channel tile) of a
@@ -93,120 +95,208 @@ __device__ inline bf16x8 frag_tr(const unsigned char* base, int p0, int tile, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool F32>
-__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
-  constexpr int ESZ = F32 ? 4 : 2, EPV = 16 / ESZ, TB = F32 ? 128 : 64;    // bytes of one 32-channel tile of a row
+// One launch computes the weight gradients of MANY convolutions (table of WgradArgs, blockIdx.z = table entry): the
+// backward plan defers every weight gradient to its end (operands stay alive), so a level's seven equal-shaped
+// convolutions fill the chip together and each needs only a few M-split workgroups.  That matters because the M-split
+// workgroups of a tile meet in global float atomics (~1.3 TB/s chip-wide): total atomic bytes = workgroups x accumulator
+// bytes per workgroup -- at ~256 workgroups per convolution the atomics took 3-5x the matrix time.
+//
+// Staging: the slot -> (row, column, channel vector) decomposition of a thread's 16-byte vectors does not depend on the
+// chunk, so it is done once (LDS offset, row, in-row byte offset per slot); per chunk and slot only the image / row of the
+// extended row list changes (~10 instructions per vector; recomputing the decomposition per vector made a 64 KB chunk cost
+// 6 us of address arithmetic at one wave per SIMD).  Loads of a round are issued together, addresses clamped not predicated.
+//
+// Matrix loop (bf16): the LDS byte address of a fragment read is (lane part) + (16-pixel step) x (row bytes): the XOR swizzle
+// looks at position bits 0..1 only and a step moves the position by 16, so the lane parts -- 2 for the dY fragment, 2 per
+// tap for X -- are computed once; per step one scalar is added.  The next step's twenty transposing reads are issued
+// before the current step's nine MFMAs (a read -> wait -> MFMA chain per tap with ~10 address instructions in front of it
+// ran the matrix pipe at 7 %).  NT = taps per entry (9: stride-1 3x3; 1: 1x1 and one tap of the stride-2 kind) is a
+// template parameter: a run-time tap count put a branch between every two MFMAs.
+// Operand pointers come out of the table (memory), i.e. as generic pointers: they are cast to the global address space --
+// flat loads count on lgkmcnt too, so every LDS wait in the matrix loop would also wait for the prefetched chunk.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;   // (a native vector: address-space-qualified loads, no struct copies)
+typedef const __attribute__((address_space(1))) u32x4* gptr16;
+template <bool F32, int NT>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab) {
+  constexpr int ESZ = F32 ? 4 : 2, EPV = 16 / ESZ, TB = F32 ? 128 : 64;    // TB: bytes of one 32-channel tile of a row
+  constexpr int SY = 8, SX = 10;                                           // staging slots per thread (host sizes chunks to fit)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WgradArgs a = tab[blockIdx.z];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwn = a.nwn, nwc = 4 / nwn;
-  const int ngr_n = (a.N + 32 * nwn - 1) / (32 * nwn);
+  const int ngr_n = (a.N + 32 * nwn - 1) / (32 * nwn), ngr_c = (a.C + 32 * nwc - 1) / (32 * nwc);
+  if ((int)blockIdx.x >= a.grid_x || (int)blockIdx.y >= ngr_n * ngr_c) return;      // (the launch grid is the table's maximum)
   const int grp_n = blockIdx.y % ngr_n, grp_c = blockIdx.y / ngr_n;
   const int nt = wave % nwn, ct = wave / nwn;
-  const int n_base = grp_n * 32 * nwn, c_base = grp_c * 32 * nwc;       // first channel of the staged operand rows
+  const int n_base = grp_n * 32 * nwn, c_base = grp_c * 32 * nwc;         // first channel of the staged operand rows
   const int n0 = n_base + 32 * nt, c0 = c_base + 32 * ct;
   const bool active = n0 < a.N && c0 < a.C;
-  const bool three = a.kind == WG_3x3;
+  constexpr bool three = NT == 9;                                          // (the host sorts entries by kind into two tables)
   const int Wp = a.W + 2;
-  const int KP = three ? ((a.nlr * Wp + 15) & ~15) : a.nlr;              // contraction positions per chunk
+  const int KP = three ? ((a.nlr * Wp + 15) & ~15) : a.nlr;                // contraction positions per chunk
   const int XP = three ? KP + 2 * Wp + 2 : KP;
-  unsigned char* Ys = smem;                                              // [KP][32 nwn]
-  unsigned char* Xs = smem + (size_t)KP * nwn * TB;                      // [XP][32 nwc]
-  const int ntaps = three ? 9 : 1;
-  const int tap_s2 = a.kind == WG_3x3_S2 ? (int)blockIdx.z : 0;          // stride-2: one tap per grid.z slice
+  unsigned char* Ys = smem;                                                // [KP][32 nwn]
+  unsigned char* Xs = smem + (size_t)KP * nwn * TB;                        // [XP][32 nwc]
 
   for (int i = tid * 16; i < (KP * nwn + XP * nwc) * TB; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  const int vn = 32 * nwn / EPV, vc = 32 * nwc / EPV;                    // 16-byte vectors per staged row
-  const unsigned char* xg = (const unsigned char*)a.x;
-  const unsigned char* yg = (const unsigned char*)a.dy;
+  const int vn = 32 * nwn / EPV, vc = 32 * nwc / EPV;                      // 16-byte vectors per staged row
+  const __attribute__((address_space(1))) unsigned char* xg = (const __attribute__((address_space(1))) unsigned char*)a.x;
+  const __attribute__((address_space(1))) unsigned char* yg = (const __attribute__((address_space(1))) unsigned char*)a.dy;
   const int HW = a.H * a.W;
-  const float inv_W = 1.0f / (float)a.W, inv_H1 = 1.0f / (float)(a.H + 1);
+  const float inv_H1 = 1.0f / (float)(a.H + 1);
+  const unsigned rowY = (unsigned)a.ldy * ESZ, rowX = (unsigned)a.C * ESZ; // bytes per pixel
+  // ---- slot tables (chunk-invariant): LDS byte offset | row << 20, byte offset inside the image row, -1 = unused slot
+  int yl[SY], yc[SY], xl[SX], xc_[SX];
+  const int nY = three ? a.nlr * a.W * vn : KP * vn, nX = three ? (a.nlr + 2) * a.W * vc : KP * vc;
+#pragma unroll
+  for (int u = 0; u < SY; ++u) {
+    const int v = tid + 256 * u;
+    const int cv = v % vn, pi = v / vn, lr = three ? pi / a.W : 0, xx = three ? pi - lr * a.W : pi;
+    const int ch = n_base + cv * EPV;
+    const int pos = three ? lr * Wp + xx + 1 : pi;
+    yl[u] = (v < nY && ch < a.ldy) ? (lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwn) | (lr << 20)) : -1;
+    yc[u] = (int)((unsigned)xx * rowY + (unsigned)ch * ESZ);
+  }
+#pragma unroll
+  for (int u = 0; u < SX; ++u) {
+    const int v = tid + 256 * u;
+    const int cv = v % vc, pi = v / vc, lr = three ? pi / a.W : 0, xx = three ? pi - lr * a.W : pi;
+    const int ch = c_base + cv * EPV;
+    const int pos = three ? lr * Wp + xx + 2 : pi;
+    xl[u] = (v < nX && ch < a.C) ? (lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwc) | (lr << 20)) : -1;
+    xc_[u] = (int)((unsigned)xx * rowX + (unsigned)ch * ESZ);
+  }
+  const int64_t M = (int64_t)a.B * HW;
+  const int dyy = a.tap / 3, dxx = a.tap % 3;                              // stride-2 kind: this entry's tap
+  // lane parts of the fragment read addresses (LDS byte addresses; bf16 path)
+  const unsigned rowLY = (unsigned)nwn * TB, rowLX = (unsigned)nwc * TB;   // LDS bytes per position
+  unsigned la[2] = {0, 0}, lb[NT][2];
+  {
+    const int grp = lane >> 4, i16 = lane & 15, h = grp >> 1, cb = 16 * (grp & 1), q = i16 >> 2, pp = i16 & 3;
+    const unsigned ybase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Ys;
+    const unsigned xbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)Xs;
+    la[0] = ybase + lds_off<false>(8 * h + q, nt, (cb + 4 * pp) * 2, nwn);
+    la[1] = ybase + lds_off<false>(8 * h + q + 4, nt, (cb + 4 * pp) * 2, nwn);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int off = three ? (t / 3) * Wp + (t % 3) : 0;
+      lb[t][0] = xbase + lds_off<false>(off + 8 * h + q, ct, (cb + 4 * pp) * 2, nwc);
+      lb[t][1] = xbase + lds_off<false>(off + 8 * h + q + 4, ct, (cb + 4 * pp) * 2, nwc);
+    }
+  }
 
-  for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
-    __syncthreads();                                                     // the previous chunk's fragments are read
+  // Software pipeline (one workgroup per CU, one wave per SIMD): the next chunk's vectors are loaded into registers before
+  // the matrix loop of the current one and written to LDS after it, so the global latency hides behind the MFMAs.
+  u32x4 vy[SY], vx[SX];
+  unsigned oky = 0, okx = 0;                                               // per-slot "real data" bits (else a zero vector)
+  auto load_chunk = [&](int chunk) {
+    oky = okx = 0;
     if (three) {
-      // ---- extended rows E0 .. E0 + nlr - 1 of the list (image b, row y) = (E / (H+1), E % (H+1)); y == H is the zero row
+      // extended rows E0 .. E0 + nlr - 1 of the list (image b, row y) = (E / (H+1), E % (H+1)); y == H is the zero row
       const int E0 = chunk * a.nlr;
-      for (int v = tid; v < a.nlr * a.W * vn; v += 256) {
-        const int cv = v % vn, pi = v / vn;
-        const int lr = (int)(((float)pi + 0.5f) * inv_W), xx = pi - lr * a.W;
-        const int E = E0 + lr;
+#pragma unroll
+      for (int u = 0; u < SY; ++u) {
+        const int E = E0 + (yl[u] >> 20);
         const int b = (int)(((float)E + 0.5f) * inv_H1), y = E - b * (a.H + 1);
-        const int ch = n_base + cv * EPV;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (y < a.H && b < a.B && ch < a.ldy) val = *(const uint4*)(yg + ((size_t)((size_t)b * HW + y * a.W + xx) * a.ldy + ch) * ESZ);
-        const int pos = lr * Wp + xx + 1;
-        *(uint4*)(Ys + lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwn)) = val;
+        const bool ok = yl[u] >= 0 && y < a.H && b < a.B;
+        oky |= (ok ? 1u : 0u) << u;
+        vy[u] = *(gptr16)(yg + (ok ? (unsigned)(b * HW + y * a.W) * rowY + (unsigned)yc[u] : 0u));
       }
-      for (int v = tid; v < (a.nlr + 2) * a.W * vc; v += 256) {
-        const int cv = v % vc, pi = v / vc;
-        const int lr = (int)(((float)pi + 0.5f) * inv_W), xx = pi - lr * a.W;
-        const int E = E0 - 1 + lr;
+#pragma unroll
+      for (int u = 0; u < SX; ++u) {
+        const int E = E0 - 1 + (xl[u] >> 20);
         const int b = E < 0 ? 0 : (int)(((float)E + 0.5f) * inv_H1), y = E < 0 ? a.H : E - b * (a.H + 1);
-        const int ch = c_base + cv * EPV;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (y < a.H && b < a.B && ch < a.C) val = *(const uint4*)(xg + ((size_t)((size_t)b * HW + y * a.W + xx) * a.C + ch) * ESZ);
-        const int pos = lr * Wp + xx + 2;
-        *(uint4*)(Xs + lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwc)) = val;
+        const bool ok = xl[u] >= 0 && y < a.H && b < a.B;
+        okx |= (ok ? 1u : 0u) << u;
+        vx[u] = *(gptr16)(xg + (ok ? (unsigned)(b * HW + y * a.W) * rowX + (unsigned)xc_[u] : 0u));
       }
     } else {
-      // ---- output pixels P0 .. P0 + KP - 1 in flattened (b, oy, ox) order; X gathered at the tap's input pixel
-      const int64_t P0 = (int64_t)chunk * KP, M = (int64_t)a.B * HW;
-      const int dyy = tap_s2 / 3, dxx = tap_s2 % 3;
-      for (int v = tid; v < KP * vn; v += 256) {
-        const int cv = v % vn, pi = v / vn;
-        const int64_t p = P0 + pi;
-        const int ch = n_base + cv * EPV;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (p < M && ch < a.ldy) val = *(const uint4*)(yg + ((size_t)p * a.ldy + ch) * ESZ);
-        *(uint4*)(Ys + lds_off<F32>(pi, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwn)) = val;
+      // output pixels P0 .. P0 + KP - 1 in flattened (b, oy, ox) order; X gathered at the tap's input pixel
+      const int64_t P0 = (int64_t)chunk * KP;
+#pragma unroll
+      for (int u = 0; u < SY; ++u) {
+        const int pi = (tid + 256 * u) / vn;
+        const bool ok = yl[u] >= 0 && P0 + pi < M;
+        oky |= (ok ? 1u : 0u) << u;
+        vy[u] = *(gptr16)(yg + (ok ? (size_t)(P0 + pi) * rowY + (unsigned)(yc[u] - pi * (int)rowY) : 0));
       }
-      for (int v = tid; v < KP * vc; v += 256) {
-        const int cv = v % vc, pi = v / vc;
+#pragma unroll
+      for (int u = 0; u < SX; ++u) {
+        const int pi = (tid + 256 * u) / vc;
         const int64_t p = P0 + pi;
-        const int ch = c_base + cv * EPV;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (p < M && ch < a.C) {
-          const int b = (int)(p / HW), r = (int)(p - (int64_t)b * HW), oy = r / a.W, ox = r - oy * a.W;
-          int yy = oy, xx = ox;
-          if (a.kind == WG_3x3_S2) { yy = 2 * oy + dyy; xx = 2 * ox + dxx; }
-          if (yy < a.Hin && xx < a.Win) val = *(const uint4*)(xg + ((size_t)(((size_t)b * a.Hin + yy) * a.Win + xx) * a.C + ch) * ESZ);
+        size_t off = 0;
+        bool ok = xl[u] >= 0 && p < M;
+        if (ok) {
+          if (a.kind == WG_3x3_S2) {
+            const int b = (int)(p / HW), r = (int)(p - (int64_t)b * HW), oy = r / a.W, ox = r - oy * a.W;
+            const int yy = 2 * oy + dyy, xx = 2 * ox + dxx;
+            ok = yy < a.Hin && xx < a.Win;
+            off = ok ? (size_t)(((size_t)b * a.Hin + yy) * a.Win + xx) * rowX + (unsigned)(xc_[u] - pi * (int)rowX) : 0;
+          } else {
+            off = (size_t)p * rowX + (unsigned)(xc_[u] - pi * (int)rowX);
+          }
         }
-        *(uint4*)(Xs + lds_off<F32>(pi, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwc)) = val;
+        okx |= (ok ? 1u : 0u) << u;
+        vx[u] = *(gptr16)(xg + off);
       }
     }
+  };
+  if ((int)blockIdx.x < a.nchunks) load_chunk(blockIdx.x);
+  for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += a.grid_x) {
+    __syncthreads();                                                       // the previous chunk's fragments are read
+#pragma unroll
+    for (int u = 0; u < SY; ++u)
+      if (yl[u] >= 0) *(u32x4*)(Ys + (yl[u] & 0xFFFFF)) = (oky >> u) & 1u ? vy[u] : (u32x4)(0u);
+#pragma unroll
+    for (int u = 0; u < SX; ++u)
+      if (xl[u] >= 0) *(u32x4*)(Xs + (xl[u] & 0xFFFFF)) = (okx >> u) & 1u ? vx[u] : (u32x4)(0u);
     __syncthreads();
+    if (chunk + a.grid_x < a.nchunks) load_chunk(chunk + a.grid_x);
     if (!active) continue;
     if constexpr (F32) {
       const int li = lane & 31, kk = lane >> 5;
       for (int p0 = 0; p0 < KP; p0 += 2) {
         const float av = *(const float*)(Ys + lds_off<true>(p0 + kk, nt, li * 4, nwn));
+        float bv[NT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          if (t < ntaps) {
-            const int off = three ? (t / 3) * Wp + (t % 3) : 0;
-            const float bv = *(const float*)(Xs + lds_off<true>(p0 + kk + off, ct, li * 4, nwc));
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-          }
+        for (int t = 0; t < NT; ++t) {
+          const int off = three ? (t / 3) * Wp + (t % 3) : 0;
+          bv[t] = *(const float*)(Xs + lds_off<true>(p0 + kk + off, ct, li * 4, nwc));
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
       }
     } else {
-      for (int p0 = 0; p0 < KP; p0 += 16) {
-        const bf16x8 af = frag_tr(Ys, p0, nt, nwn, lane);
+      typedef __attribute__((address_space(3))) s16x4* lptr;
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      auto rd = [&](unsigned addr0, unsigned addr1) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uintptr_t)addr0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uintptr_t)addr1);
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      bf16x8 af = rd(la[0], la[1]), bfr[NT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          if (t < ntaps) {
-            const int off = three ? (t / 3) * Wp + (t % 3) : 0;
-            const bf16x8 bfr = frag_tr(Xs, p0 + off, ct, nwc, lane);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
-          }
-        }
+      for (int t = 0; t < NT; ++t) bfr[t] = rd(lb[t][0], lb[t][1]);
+      for (int p0 = 0; p0 < KP; p0 += 16) {
+        const bool more = p0 + 16 < KP;
+        const unsigned sy = (unsigned)(p0 + 16) * rowLY, sx = (unsigned)(p0 + 16) * rowLX;
+        bf16x8 an = af, bn[NT];
+        if (more) an = rd(la[0] + sy, la[1] + sy);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bn[t] = more ? rd(lb[t][0] + sx, lb[t][1] + sx) : bfr[t];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[t], acc[t], 0, 0, 0);
+        af = an;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bfr[t] = bn[t];
       }
     }
   }
@@ -215,15 +305,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
   // the wave is two 128-byte row segments, the float-atomic unit that runs at the full rate
   const int col = c0 + (lane & 31), g = lane >> 5;
   if (col < a.C) {
+    __attribute__((address_space(1))) float* gw = (__attribute__((address_space(1))) float*)a.gw;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (t < ntaps) {
-        const int tap = a.kind == WG_3x3_S2 ? tap_s2 : t;
+    for (int t = 0; t < NT; ++t) {
+      const int tap = a.kind == WG_3x3_S2 ? a.tap : t;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          if (n < a.N) atomicAdd(a.gw + (size_t)n * a.Ktot + a.koff + tap * a.C + col, acc[t][r]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (n < a.N) __hip_atomic_fetch_add(gw + (size_t)n * a.Ktot + a.koff + tap * a.C + col, acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -231,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 
 // ============================================================================ GroupNorm (+Swish, +dropout) backward
 // forward (unet.py:103-133): z = gamma xhat + beta, xhat = (x - mean_g) rstd_g ; a = swish(z) [* keep / (1 - p)]
-// backward: dz = dA swish'(z) [* keep / (1 - p)]
+// backward (k_gn_bwd_sums, k_gn_bwd_dx): dz = dA swish'(z) [* keep / (1 - p)]
 //           dX = rstd_g ( gamma dz - m1_g - xhat m2_g ),  m1_g = mean_g(gamma dz), m2_g = mean_g(gamma dz xhat)
 //           dgamma[c] = sum_{b,p} dz xhat ;  dbeta[c] = sum_{b,p} dz
 struct GnBwdArgs {
@@ -244,23 +333,8 @@ struct GnBwdArgs {
   float* d1_f32; unsigned short* d1_bf16; int acc1;          // gradient w.r.t. source 1 (acc: add to what is there)
   float* d2_f32; unsigned short* d2_bf16; int acc2;
   float drop_p; const uint64_t* rng; uint64_t layer;         // dropout after the activation (ResBlock, unet.py:113,132): rng = {seed, step}
+  float* dsum_bn; int dsum_stride; float* dsum_n;            // optional (single source): sum_p dX per (sample, channel) -> [b*stride + c], and += over samples
 };
-__device__ inline void gn_bwd_channel_table(const GnBwdArgs& a, int b, float* mean, float* rstd) {
-  const int C = a.C1 + a.C2, cg = C / a.G;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cg;
-    double s = 0.0, q = 0.0;
-    for (int j = g * cg; j < (g + 1) * cg; ++j) {
-      const double* st = j < a.C1 ? a.st1 + ((size_t)b * a.C1 + j) * 2 : a.st2 + ((size_t)b * a.C2 + (j - a.C1)) * 2;
-      s += st[0]; q += st[1];
-    }
-    const double n = (double)cg * (double)a.HW;
-    const double m = s / n;
-    const double var = fmax(q / n - m * m, 0.0);
-    mean[c] = (float)m;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
-  }
-}
 // keep-mask of the 8 channels starting at element index e0 (multiple of 8): two Philox blocks
 __device__ inline unsigned drop_keep8(uint64_t seed, uint64_t offset, uint64_t e0, float p) {
   const u4 r0 = philox_row(seed, offset, e0 >> 2, 0x44524F50u), r1 = philox_row(seed, offset, (e0 >> 2) + 1, 0x44524F50u);
@@ -270,102 +344,190 @@ __device__ inline unsigned drop_keep8(uint64_t seed, uint64_t offset, uint64_t e
   for (int j = 0; j < 8; ++j) m |= (u01(w[j]) >= p ? 1u : 0u) << j;
   return m;
 }
-// dz and xhat of one 8-channel vector
-__device__ inline void gn_bwd_vec(const GnBwdArgs& a, int b, int px, int c0, const float* mean, const float* rstd, float (&dz)[8],
-                                  float (&xh)[8]) {
+// raw operands of one 8-channel vector: the forward input x and the incoming gradient dA (two 16-byte loads)
+struct GnVecRaw { float x[8], da[8]; size_t oo; };
+__device__ inline void gn_bwd_load(const GnBwdArgs& a, int b, int px, int c0, GnVecRaw& r) {
   const int C = a.C1 + a.C2;
   const bool first = c0 < a.C1;
   const int cc = first ? c0 : c0 - a.C1, Cs = first ? a.C1 : a.C2;
-  const size_t off = ((size_t)b * a.HW + px) * Cs + cc;
-  float x[8], da[8];
-  load8(first ? a.s1_f32 : a.s2_f32, first ? a.s1_bf16 : a.s2_bf16, off, x);
-  const size_t oo = ((size_t)b * a.HW + px) * C + c0;
-  load8(a.da_f32, a.da_bf16, oo, da);
+  load8(first ? a.s1_f32 : a.s2_f32, first ? a.s1_bf16 : a.s2_bf16, ((size_t)b * a.HW + px) * Cs + cc, r.x);
+  r.oo = ((size_t)b * a.HW + px) * C + c0;
+  load8(a.da_f32, a.da_bf16, r.oo, r.da);
+}
+// dz and xhat from them; tm / tr / tg / tb = mean, rstd, gamma, beta of the thread's eight channels (registers: a thread keeps
+// one channel vector for all its pixels; reading them from LDS per element was most of this kernel's time)
+__device__ inline void gn_bwd_math(const GnBwdArgs& a, const float (&tm)[8], const float (&tr)[8], const float (&tg)[8], const float (&tb)[8],
+                                   const GnVecRaw& r, float (&dz)[8], float (&xh)[8]) {
   unsigned keep = 0xFFu;
   float inv_keep = 1.0f;
-  if (a.drop_p > 0.0f) { keep = drop_keep8(a.rng[0], a.rng[1] * 4096u + a.layer, oo, a.drop_p); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  if (a.drop_p > 0.0f) { keep = drop_keep8(a.rng[0], a.rng[1] * 4096u + a.layer, r.oo, a.drop_p); inv_keep = 1.0f / (1.0f - a.drop_p); }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    xh[j] = (x[j] - mean[c0 + j]) * rstd[c0 + j];
-    float d = da[j];
+    xh[j] = (r.x[j] - tm[j]) * tr[j];
+    float d = r.da[j];
     if (a.drop_p > 0.0f) d = (keep >> j) & 1u ? d * inv_keep : 0.0f;
     if (a.swish) {
-      const float z = fmaf(a.gamma[c0 + j], xh[j], a.beta[c0 + j]);
-      const float sg = 1.0f / (1.0f + expf(-z));
+      const float z = fmaf(tg[j], xh[j], tb[j]);
+      const float sg = a.da_bf16 ? __builtin_amdgcn_rcpf(1.0f + __expf(-z)) : 1.0f / (1.0f + expf(-z));
       d *= sg * (1.0f + z * (1.0f - sg));
     }
     dz[j] = d;
   }
 }
-// pass 1: per-(sample, channel) sums.  grid (pixel slices, B); thread = (pixel lane, 8-channel vector)
-__global__ __launch_bounds__(256) void k_gn_bwd_reduce(const GnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int C = a.C1 + a.C2, b = blockIdx.y, vpp = C / 8;
-  float* mean = sm; float* rstd = sm + C; float* part = sm + 2 * C;          // part: [2][C] block sums
-  gn_bwd_channel_table(a, b, mean, rstd);
-  for (int i = threadIdx.x; i < 2 * C; i += 256) part[i] = 0.0f;
-  __syncthreads();
-  const int per = (a.HW + gridDim.x - 1) / gridDim.x, p_lo = blockIdx.x * per, p_hi = min(p_lo + per, a.HW);
-  // a thread keeps ONE channel vector and strides over the slice's pixels (256 / vpp pixel lanes; C <= 2048)
-  const int lanes = 256 / vpp, cv = threadIdx.x % vpp, pl = threadIdx.x / vpp;
-  if (pl < lanes) {
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.0f; s2[j] = 0.0f; }
-    for (int px = p_lo + pl; px < p_hi; px += lanes) {
-      float dz[8], xh[8];
-      gn_bwd_vec(a, b, px, cv * 8, mean, rstd, dz, xh);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s1[j] += dz[j]; s2[j] = fmaf(dz[j], xh[j], s2[j]); }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(part + cv * 8 + j, s1[j]);
-      atomicAdd(part + C + cv * 8 + j, s2[j]);
-    }
+// Two launches, both with a workgroup per (sample, slice of pixels) and ALL channels: a wave's 16-byte loads then walk whole
+// NHWC pixel rows (a workgroup per channel block -- which would let one launch do everything -- reads 16 bytes of every
+// C*2-byte row per lane: uncoalesced, 0.6-1.0 TB/s measured).  thread = (pixel lane, channel vector cv = tid % (C/8)): its
+// eight channels are fixed, so mean / rstd / gamma / beta (and the group means in pass 2) sit in registers; four pixels'
+// loads are in flight per thread; every channel's statistics are fetched in one round trip and summed per group from LDS.
+//   pass 1  k_gn_bwd_sums: per-(sample, channel) sums of dz and dz*xhat: block reduction in LDS, one atomic per channel,
+//           moment and workgroup into `sums` (zeroed by the caller)
+//   pass 2  k_gn_bwd_dx:   group means from `sums`, dX (+= existing gradient); block x = 0 also writes the closed-form
+//           per-sample sums of dX (time-projection / conv1-bias gradients)
+struct GnRegs { float tm[8], tr[8], tg[8], tb[8]; };
+__device__ inline void gn_bwd_setup(const GnBwdArgs& a, int b, float* tab, double* cst, int cv, GnRegs& R) {
+  const int C = a.C1 + a.C2, cg = C / a.G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double* st = c < a.C1 ? a.st1 + ((size_t)b * a.C1 + c) * 2 : a.st2 + ((size_t)b * a.C2 + (c - a.C1)) * 2;
+    cst[2 * c] = st[0]; cst[2 * c + 1] = st[1];
+    tab[2 * C + c] = a.gamma[c];
+    tab[3 * C + c] = a.beta[c];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int c = i % C, which = i / C;
-    atomicAdd(a.sums + ((size_t)b * C + c) * 2 + which, part[i]);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gl = (c / cg) * cg;
+    double s = 0.0, q = 0.0;
+    for (int jc = gl; jc < gl + cg; ++jc) { s += cst[2 * jc]; q += cst[2 * jc + 1]; }
+    const double n = (double)cg * (double)a.HW, m = s / n, var = fmax(q / n - m * m, 0.0);
+    tab[c] = (float)m;
+    tab[C + c] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    R.tm[j] = tab[8 * cv + j]; R.tr[j] = tab[C + 8 * cv + j]; R.tg[j] = tab[2 * C + 8 * cv + j]; R.tb[j] = tab[3 * C + 8 * cv + j];
   }
 }
-// pass 2: dX.  grid (vector slices, B)
-__global__ __launch_bounds__(256) void k_gn_bwd_apply(const GnBwdArgs a) {
+__global__ __launch_bounds__(256) void k_gn_bwd_sums(const GnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int C = a.C1 + a.C2, b = blockIdx.y, vpp = C / 8;
+  float* tab = sm;                                   // [4][C]
+  double* cst = (double*)(sm + 4 * C);               // [C][2]
+  float* red = sm + 8 * C;                           // [256][16]
+  const int lanes = 256 / vpp, cv = threadIdx.x % vpp, pl = threadIdx.x / vpp;          // C <= 2048
+  const bool worker = pl < lanes;
+  const int per = (a.HW + gridDim.x - 1) / gridDim.x, p_lo = blockIdx.x * per, p_hi = min(p_lo + per, a.HW);
+  GnVecRaw r[4];
+  if (worker && p_lo < p_hi) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gn_bwd_load(a, b, min(p_lo + pl + u * lanes, p_hi - 1), cv * 8, r[u]);
+  }
+  GnRegs R;
+  gn_bwd_setup(a, b, tab, cst, cv, R);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.0f; s2[j] = 0.0f; }
+  if (worker) {
+    for (int px0 = p_lo + pl; px0 < p_hi; px0 += 4 * lanes) {
+      if (px0 != p_lo + pl) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gn_bwd_load(a, b, min(px0 + u * lanes, p_hi - 1), cv * 8, r[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (px0 + u * lanes < p_hi) {
+          float dz[8], xh[8];
+          gn_bwd_math(a, R.tm, R.tr, R.tg, R.tb, r[u], dz, xh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s1[j] += dz[j]; s2[j] = fmaf(dz[j], xh[j], s2[j]); }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[threadIdx.x * 16 + j] = s1[j]; red[threadIdx.x * 16 + 8 + j] = s2[j]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * C; t += 256) {                     // output (which, channel): sum over the pixel lanes
+    const int which = t / C, c = t % C, vv = c / 8, j = c % 8;
+    float acc = 0.0f;
+    for (int p = 0; p < lanes; ++p) acc += red[(p * vpp + vv) * 16 + which * 8 + j];
+    atomicAdd(a.sums + ((size_t)b * C + c) * 2 + which, acc);
+  }
+}
+__global__ __launch_bounds__(256) void k_gn_bwd_dx(const GnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = a.C1 + a.C2, b = blockIdx.y, vpp = C / 8, cg = C / a.G;
-  float* mean = sm; float* rstd = sm + C; float* m1 = sm + 2 * C; float* m2 = sm + 3 * C;
-  gn_bwd_channel_table(a, b, mean, rstd);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int g = c / cg;
-    float t1 = 0.0f, t2 = 0.0f;
-    for (int j = g * cg; j < (g + 1) * cg; ++j) {
-      t1 = fmaf(a.gamma[j], a.sums[((size_t)b * C + j) * 2], t1);
-      t2 = fmaf(a.gamma[j], a.sums[((size_t)b * C + j) * 2 + 1], t2);
+  float* tab = sm;                                   // [4][C]
+  double* cst = (double*)(sm + 4 * C);               // [C][2]
+  float* ss = sm + 8 * C;                            // [C][2] this sample's sums, then m1[C], m2[C]
+  const int lanes = 256 / vpp, cv = threadIdx.x % vpp, pl = threadIdx.x / vpp;
+  const bool worker = pl < lanes;
+  const int per = (a.HW + gridDim.x - 1) / gridDim.x, p_lo = blockIdx.x * per, p_hi = min(p_lo + per, a.HW);
+  const int c0 = cv * 8;
+  const bool first = c0 < a.C1;
+  const int cc = first ? c0 : c0 - a.C1, Cs = first ? a.C1 : a.C2;
+  float* const df = first ? a.d1_f32 : a.d2_f32;
+  unsigned short* const dh = first ? a.d1_bf16 : a.d2_bf16;
+  const bool accum = first ? a.acc1 : a.acc2;
+  GnVecRaw r[4];
+  float old[4][8];
+  if (worker && p_lo < p_hi) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = min(p_lo + pl + u * lanes, p_hi - 1);
+      gn_bwd_load(a, b, px, c0, r[u]);
+      if (accum) load8(df, dh, ((size_t)b * a.HW + px) * Cs + cc, old[u]);
     }
+  }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) ss[i] = a.sums[(size_t)b * C * 2 + i];
+  GnRegs R;
+  gn_bwd_setup(a, b, tab, cst, cv, R);               // (its barriers also publish ss)
+  float* m1 = ss + 2 * C;
+  float* m2 = m1 + C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int gl = (c / cg) * cg;
+    float t1 = 0.0f, t2 = 0.0f;
+    for (int jc = gl; jc < gl + cg; ++jc) { t1 = fmaf(tab[2 * C + jc], ss[2 * jc], t1); t2 = fmaf(tab[2 * C + jc], ss[2 * jc + 1], t2); }
     const float inv = 1.0f / ((float)cg * (float)a.HW);
     m1[c] = t1 * inv; m2[c] = t2 * inv;
   }
   __syncthreads();
-  const int64_t nv = (int64_t)a.HW * vpp;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256) {
-    const int px = (int)(v / vpp), c0 = (int)(v % vpp) * 8;
-    float dz[8], xh[8], dx[8];
-    gn_bwd_vec(a, b, px, c0, mean, rstd, dz, xh);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dx[j] = rstd[c0 + j] * (a.gamma[c0 + j] * dz[j] - m1[c0 + j] - xh[j] * m2[c0 + j]);
-    const bool first = c0 < a.C1;
-    const int cc = first ? c0 : c0 - a.C1, Cs = first ? a.C1 : a.C2;
-    const size_t off = ((size_t)b * a.HW + px) * Cs + cc;
-    float* df = first ? a.d1_f32 : a.d2_f32;
-    unsigned short* dh = first ? a.d1_bf16 : a.d2_bf16;
-    if (first ? a.acc1 : a.acc2) {
-      float old[8];
-      load8(df, dh, off, old);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dx[j] += old[j];
+  if (blockIdx.x == 0 && (a.dsum_bn || a.dsum_n)) {
+    // sum over the sample's pixels of dX, in closed form from the sums (the input is conv1's output + bias + time projection:
+    // this IS the gradient of the time projection, unet.py:110,131, and its sum over samples the bias gradient):
+    //   sum_p dX = rstd (gamma S1 - HW m1 - m2 sum_p xhat),   sum_p xhat = (sum_p x - HW mean) rstd
+    for (int c = threadIdx.x; c < a.C1; c += 256) {
+      const float sxh = ((float)cst[2 * c] - (float)a.HW * tab[c]) * tab[C + c];
+      const float val = tab[C + c] * (tab[2 * C + c] * ss[2 * c] - (float)a.HW * m1[c] - m2[c] * sxh);
+      if (a.dsum_bn) a.dsum_bn[(size_t)b * a.dsum_stride + c] = val;
+      if (a.dsum_n) atomicAdd(a.dsum_n + c, val);
     }
-    store8(df, dh, off, dx);
+  }
+  if (!worker) return;
+  float sc[8], k1[8], k2[8];                                       // dX = sc dz - k1 - xhat k2
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = R.tr[j] * R.tg[j]; k1[j] = R.tr[j] * m1[c0 + j]; k2[j] = R.tr[j] * m2[c0 + j]; }
+  for (int px0 = p_lo + pl; px0 < p_hi; px0 += 4 * lanes) {
+    if (px0 != p_lo + pl) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int px = min(px0 + u * lanes, p_hi - 1);
+        gn_bwd_load(a, b, px, c0, r[u]);
+        if (accum) load8(df, dh, ((size_t)b * a.HW + px) * Cs + cc, old[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = px0 + u * lanes;
+      if (px >= p_hi) continue;
+      float dz[8], xh[8], dx[8];
+      gn_bwd_math(a, R.tm, R.tr, R.tg, R.tb, r[u], dz, xh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dx[j] = fmaf(-xh[j], k2[j], fmaf(sc[j], dz[j], -k1[j]));
+        if (accum) dx[j] += old[u][j];
+      }
+      store8(df, dh, ((size_t)b * a.HW + px) * Cs + cc, dx);
+    }
   }
 }
 
@@ -414,13 +576,20 @@ __global__ __launch_bounds__(256) void k_colsum(const float* f, const unsigned s
   }
 }
 
-// out[j] (+)= sum_b in[b * bstride + j * jstride]  (GroupNorm dgamma / dbeta from the per-sample sums, ...)
+// out[j] (+)= sum_b in[b * bstride + j * jstride]  (GroupNorm dgamma / dbeta from the per-sample sums, ...): workgroup = 64
+// outputs x 4 batch lanes
 __global__ __launch_bounds__(256) void k_sum_batch(const float* in, int B, int64_t bstride, int jstride, int n, float* out, int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ float part[4][64];
+  const int jl = threadIdx.x & 63, bl = threadIdx.x >> 6, j = blockIdx.x * 64 + jl;
   float s = 0.0f;
-  for (int b = 0; b < B; ++b) s += in[(size_t)b * bstride + (size_t)j * jstride];
-  out[j] = accumulate ? out[j] + s : s;
+  if (j < n)
+    for (int b = bl; b < B; b += 4) s += in[(size_t)b * bstride + (size_t)j * jstride];
+  part[bl][jl] = s;
+  __syncthreads();
+  if (bl == 0 && j < n) {
+    const float t = (part[0][jl] + part[1][jl]) + (part[2][jl] + part[3][jl]);
+    out[j] = accumulate ? out[j] + t : t;
+  }
 }
 
 // dst (+)= src over n elements (n % 8 == 0): the identity-skip / residual branch of a gradient
@@ -436,6 +605,26 @@ __global__ __launch_bounds__(256) void k_accumulate(const float* sf, const unsig
       for (int j = 0; j < 8; ++j) x[j] += o[j];
     }
     store8(df, dh, (size_t)v * 8, x);
+  }
+}
+
+// The same reduction for a TABLE of jobs in one launch (the backward plan's ~80 small sums: GroupNorm dgamma / dbeta from the
+// per-sample sums, bias gradients out of the weight-gradient launch's ones-column, copies for parameters that share a
+// gradient): workgroup = one job's 64 outputs x 4 batch lanes (a thread per output walking B samples serially was 10 us of
+// dependent-load latency per launch, ~1 ms per training step).
+struct SumJob { const float* in; float* out; int64_t bstride; int B, jstride, n, accumulate, j0, pad_; };
+__global__ __launch_bounds__(256) void k_sum_jobs(const SumJob* __restrict__ jobs) {
+  __shared__ float part[4][64];
+  const SumJob q = jobs[blockIdx.x];
+  const int jl = threadIdx.x & 63, bl = threadIdx.x >> 6, j = q.j0 + jl;
+  float s = 0.0f;
+  if (j < q.n)
+    for (int b = bl; b < q.B; b += 4) s += q.in[(size_t)b * q.bstride + (size_t)j * q.jstride];
+  part[bl][jl] = s;
+  __syncthreads();
+  if (bl == 0 && j < q.n) {
+    const float t = (part[0][jl] + part[1][jl]) + (part[2][jl] + part[3][jl]);
+    q.out[j] = q.accumulate ? q.out[j] + t : t;
   }
 }
 
@@ -550,53 +739,62 @@ __global__ __launch_bounds__(256) void k_attn_small_bwd(const AttnBwdArgs a) {
 }
 
 // ============================================================================ first conv weight gradient (unet.py:343, C_in = 1..4)
-// dW0[n][ci][tap] = sum_{b,p} dY[b,p,n] xc[b,ci,p + off(tap)] with xc the centred integer state; fp32 FMA, atomics
+// dW0[n][ci][tap] = sum_{b,p} dY[b,p,n] xc[b,ci,p + off(tap)] with xc the centred integer state.  A workgroup takes a band of
+// image rows of one sample: the centred input band (+ halo, zero border) is converted once into LDS, thread = (channel n,
+// pixel lane) reads dY coalesced over n and the nine taps as LDS broadcasts; per-workgroup partial sums leave as plain
+// stores ([workgroup][Cout*K | Cout]) and k_sum_batch adds the workgroups up (no atomics on the 960-word result).
 struct FirstWgradArgs { const int64_t* x64; const int32_t* x32; float lo, hi; const float* dy_f32; const unsigned short* dy_bf16;
-                        int B, Cin, H, W, Cout; float* gw; float* gbias; };
+                        int B, Cin, H, W, Cout; float* gw; float* gbias; float* partial; };
+__host__ __device__ inline int first_wgrad_bands(int H) { return H >= 16 ? 8 : H >= 8 ? 4 : 1; }
 __global__ __launch_bounds__(256) void k_first_conv_wgrad(const FirstWgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];               // [Cout][Cin*9 + 1] block sums
-  const int K = a.Cin * 9, HW = a.H * a.W, b = blockIdx.y;
-  for (int i = threadIdx.x; i < a.Cout * (K + 1); i += 256) sm[i] = 0.0f;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = a.Cin * 9, HW = a.H * a.W, b = blockIdx.y, Wp = a.W + 2;
+  const int rows_per = (a.H + gridDim.x - 1) / gridDim.x, y_lo = blockIdx.x * rows_per, y_hi = min(y_lo + rows_per, a.H);
+  float* slab = sm;                                                       // [Cin][rows_per + 2][W + 2]
+  float* acc_s = sm + a.Cin * (rows_per + 2) * Wp;                        // [Cout][K + 1]
+  for (int i = threadIdx.x; i < a.Cout * (K + 1); i += 256) acc_s[i] = 0.0f;
+  for (int idx = threadIdx.x; idx < a.Cin * (rows_per + 2) * Wp; idx += 256) {
+    const int ci = idx / ((rows_per + 2) * Wp), rem = idx % ((rows_per + 2) * Wp), ry = rem / Wp, xc = rem % Wp;
+    const int yy = y_lo - 1 + ry, xx = xc - 1;
+    float v = 0.0f;
+    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+      const size_t o = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
+      const float raw = a.x64 ? (float)a.x64[o] : (float)a.x32[o];
+      v = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
+    }
+    slab[idx] = v;
+  }
   __syncthreads();
-  const int per = (HW + gridDim.x - 1) / gridDim.x, p_lo = blockIdx.x * per, p_hi = min(p_lo + per, HW);
-  // thread = (channel n, pixel lane); Cout <= 256
   const int lanes = max(256 / a.Cout, 1), n = threadIdx.x % a.Cout, pl = threadIdx.x / a.Cout;
-  if (pl < lanes) {
+  if (pl < lanes && y_lo < y_hi) {
     float acc[37];
 #pragma unroll
     for (int i = 0; i < 37; ++i) acc[i] = 0.0f;
+    const int p_lo = y_lo * a.W, p_hi = y_hi * a.W;
     for (int p = p_lo + pl; p < p_hi; p += lanes) {
       const size_t o = ((size_t)b * HW + p) * a.Cout + n;
       const float g = a.dy_f32 ? a.dy_f32[o] : bf_lo((unsigned)a.dy_bf16[o]);
-      const int y = p / a.W, x = p % a.W;
+      const int y = p / a.W - y_lo, x = p % a.W;
       acc[36] += g;
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci) {
         if (ci < a.Cin) {
+          const float* row = slab + (ci * (rows_per + 2) + y) * Wp + x;   // (y, x) of the band = slab row y + 1, column x + 1
 #pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            float xv = 0.0f;
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-              const size_t xo = (((size_t)b * a.Cin + ci) * a.H + yy) * a.W + xx;
-              const float raw = a.x64 ? (float)a.x64[xo] : (float)a.x32[xo];
-              xv = 2.0f * ((raw - a.lo) / (a.hi - a.lo)) - 1.0f;
-            }
-            acc[ci * 9 + t] = fmaf(g, xv, acc[ci * 9 + t]);
-          }
+          for (int t = 0; t < 9; ++t) acc[ci * 9 + t] = fmaf(g, row[(t / 3) * Wp + (t % 3)], acc[ci * 9 + t]);
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < 36; ++i)
-      if (i < K) atomicAdd(sm + n * (K + 1) + i, acc[i]);
-    atomicAdd(sm + n * (K + 1) + K, acc[36]);
+      if (i < K) atomicAdd(acc_s + n * (K + 1) + i, acc[i]);
+    atomicAdd(acc_s + n * (K + 1) + K, acc[36]);
   }
   __syncthreads();
+  float* out = a.partial + ((size_t)b * gridDim.x + blockIdx.x) * a.Cout * (K + 1);
   for (int i = threadIdx.x; i < a.Cout * (K + 1); i += 256) {
     const int nn = i / (K + 1), kk = i % (K + 1);
-    if (kk < K) atomicAdd(a.gw + (size_t)nn * K + kk, sm[i]);          // torch layout [Cout][Cin][3][3]
-    else if (a.gbias) atomicAdd(a.gbias + nn, sm[i]);
+    out[kk < K ? nn * K + kk : a.Cout * K + nn] = acc_s[i];              // [Cout*K weights (torch layout) | Cout bias sums]
   }
 }
 
@@ -674,33 +872,57 @@ static inline int grid_for(int64_t items, int cap = 4096) {
   return (int)(g < 1 ? 1 : g > cap ? cap : g);
 }
 
-extern "C" int ctdd_unet_wgrad(const void* args_, int f32, int grid_x, void* stream) {
-  const WgradArgs& a = *(const WgradArgs*)args_;
-  CTDD_REQUIRE(a.x && a.dy && a.gw, CTDD_EINVAL, "wgrad: null operand");
-  CTDD_REQUIRE(a.nwn == 1 || a.nwn == 2 || a.nwn == 4, CTDD_EINVAL, "wgrad: nwn=%d", a.nwn);
-  const int epv = f32 ? 4 : 8;
-  CTDD_REQUIRE(a.C % epv == 0 && a.ldy % epv == 0 && a.N <= a.ldy, CTDD_EINVAL, "wgrad: C=%d ldy=%d N=%d need %d-element vectors", a.C, a.ldy, a.N, epv);
-  CTDD_REQUIRE(a.kind == WG_3x3 || a.kind == WG_1x1 || a.kind == WG_3x3_S2, CTDD_EINVAL, "wgrad: kind=%d", a.kind);
-  CTDD_REQUIRE(a.nlr > 0 && a.nchunks > 0 && grid_x > 0, CTDD_EINVAL, "wgrad: nlr=%d nchunks=%d grid=%d", a.nlr, a.nchunks, grid_x);
-  if (a.kind == WG_3x3) CTDD_REQUIRE(a.Hin == a.H && a.Win == a.W, CTDD_EINVAL, "wgrad: 3x3 kind is stride 1");
-  else CTDD_REQUIRE(a.nlr % 16 == 0, CTDD_EINVAL, "wgrad: pixels per chunk must be a multiple of 16");
-  const int tb = f32 ? 128 : 64, nwc = 4 / a.nwn, Wp = a.W + 2;
-  const int KP = a.kind == WG_3x3 ? ((a.nlr * Wp + 15) & ~15) : a.nlr;
-  const int XP = a.kind == WG_3x3 ? KP + 2 * Wp + 2 : KP;
-  const size_t lds = ((size_t)KP * a.nwn + (size_t)XP * nwc) * tb;
-  CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "wgrad: %zu bytes of LDS", lds);
-  const int ngr_n = (a.N + 32 * a.nwn - 1) / (32 * a.nwn), ngr_c = (a.C + 32 * nwc - 1) / (32 * nwc);
-  dim3 g((unsigned)grid_x, (unsigned)(ngr_n * ngr_c), a.kind == WG_3x3_S2 ? 9u : 1u);
-  hipStream_t st = (hipStream_t)stream;
-  if (f32) {
-    static bool done[16] = {};
-    ensure_lds_ceiling((const void*)k_wgrad<true>, done);
-    hipLaunchKernelGGL(k_wgrad<true>, g, dim3(256), lds, st, a);
-  } else {
-    static bool done[16] = {};
-    ensure_lds_ceiling((const void*)k_wgrad<false>, done);
-    hipLaunchKernelGGL(k_wgrad<false>, g, dim3(256), lds, st, a);
+// table: `n` ctdd_wgrad_args in DEVICE memory (table_host: the same entries in host memory, for validation and sizing).
+// All entries of one call are of one tap count: CTDD_WG_3x3 entries (nine taps), or CTDD_WG_1x1 / CTDD_WG_3x3_S2 entries (one).
+extern "C" int ctdd_unet_wgrad(const void* table_dev, const void* table_host, int n, int f32, void* stream) {
+  CTDD_REQUIRE(table_dev && table_host && n > 0 && n <= 65535, CTDD_EINVAL, "wgrad: empty table / n=%d", n);
+  const WgradArgs* t = (const WgradArgs*)table_host;
+  const int epv = f32 ? 4 : 8, tb = f32 ? 128 : 64;
+  size_t lds = 0;
+  int gx = 1, gy = 1;
+  const bool nine = t[0].kind == WG_3x3;
+  for (int i = 0; i < n; ++i) {
+    const WgradArgs& a = t[i];
+    CTDD_REQUIRE(a.x && a.dy && a.gw, CTDD_EINVAL, "wgrad[%d]: null operand", i);
+    CTDD_REQUIRE(a.nwn == 1 || a.nwn == 2 || a.nwn == 4, CTDD_EINVAL, "wgrad[%d]: nwn=%d", i, a.nwn);
+    CTDD_REQUIRE(a.C % epv == 0 && a.ldy % epv == 0 && a.N <= a.ldy, CTDD_EINVAL, "wgrad[%d]: C=%d ldy=%d N=%d need %d-element vectors", i, a.C,
+                 a.ldy, a.N, epv);
+    CTDD_REQUIRE(a.kind == WG_3x3 || a.kind == WG_1x1 || a.kind == WG_3x3_S2, CTDD_EINVAL, "wgrad[%d]: kind=%d", i, a.kind);
+    CTDD_REQUIRE((a.kind == WG_3x3) == nine, CTDD_EINVAL, "wgrad[%d]: a table holds nine-tap entries or one-tap entries, not both", i);
+    CTDD_REQUIRE(a.nlr > 0 && a.nchunks > 0 && a.grid_x > 0 && a.tap >= 0 && a.tap < 9, CTDD_EINVAL, "wgrad[%d]: nlr=%d nchunks=%d grid=%d", i,
+                 a.nlr, a.nchunks, a.grid_x);
+    CTDD_REQUIRE((size_t)a.B * a.Hin * a.Win * a.C * (f32 ? 4 : 2) < (1ull << 32) && (size_t)a.B * a.H * a.W * a.ldy * (f32 ? 4 : 2) < (1ull << 32),
+                 CTDD_ERANGE, "wgrad[%d]: operand beyond 32-bit byte offsets", i);
+    const int nwc = 4 / a.nwn, Wp = a.W + 2, vn = 32 * a.nwn / epv, vc = 32 * nwc / epv;
+    int KP, XP, nY, nX;
+    if (a.kind == WG_3x3) {
+      CTDD_REQUIRE(a.Hin == a.H && a.Win == a.W, CTDD_EINVAL, "wgrad[%d]: 3x3 kind is stride 1", i);
+      KP = (a.nlr * Wp + 15) & ~15; XP = KP + 2 * Wp + 2; nY = a.nlr * a.W * vn; nX = (a.nlr + 2) * a.W * vc;
+      CTDD_REQUIRE(a.nlr < 2048, CTDD_ERANGE, "wgrad[%d]: nlr=%d", i, a.nlr);
+    } else {
+      CTDD_REQUIRE(a.nlr % 16 == 0, CTDD_EINVAL, "wgrad[%d]: pixels per chunk must be a multiple of 16", i);
+      KP = XP = a.nlr; nY = KP * vn; nX = KP * vc;
+    }
+    CTDD_REQUIRE(nY <= 256 * 8 && nX <= 256 * 10, CTDD_ERANGE, "wgrad[%d]: chunk of %d + %d vectors exceeds the staging slots (8 + 10 per thread)", i, nY, nX);
+    const size_t l = ((size_t)KP * a.nwn + (size_t)XP * nwc) * tb;
+    CTDD_REQUIRE(l <= 160 * 1024 && l < (1u << 20), CTDD_ERANGE, "wgrad[%d]: %zu bytes of LDS", i, l);
+    if (l > lds) lds = l;
+    const int groups = ((a.N + 32 * a.nwn - 1) / (32 * a.nwn)) * ((a.C + 32 * nwc - 1) / (32 * nwc));
+    if (a.grid_x > gx) gx = a.grid_x;
+    if (groups > gy) gy = groups;
   }
+  dim3 g((unsigned)gx, (unsigned)gy, (unsigned)n);
+  hipStream_t st = (hipStream_t)stream;
+  const WgradArgs* td = (const WgradArgs*)table_dev;
+#define CTDD_WGRAD_LAUNCH(F_, NT_)                                          \
+  {                                                                         \
+    static bool done[16] = {};                                              \
+    ensure_lds_ceiling((const void*)k_wgrad<F_, NT_>, done);                \
+    hipLaunchKernelGGL((k_wgrad<F_, NT_>), g, dim3(256), lds, st, td);      \
+  }
+  if (f32) { if (nine) CTDD_WGRAD_LAUNCH(true, 9) else CTDD_WGRAD_LAUNCH(true, 1) }
+  else { if (nine) CTDD_WGRAD_LAUNCH(false, 9) else CTDD_WGRAD_LAUNCH(false, 1) }
+#undef CTDD_WGRAD_LAUNCH
   return finish_launch("k_wgrad");
 }
 
@@ -709,15 +931,16 @@ extern "C" int ctdd_unet_gn_bwd(const void* args_, void* stream) {
   const int C = a.C1 + a.C2;
   CTDD_REQUIRE(C % 8 == 0 && a.C1 % 8 == 0 && C % a.G == 0 && C <= 2048 && a.sums, CTDD_EINVAL, "gn bwd: C=%d C1=%d G=%d", C, a.C1, a.G);
   CTDD_REQUIRE((a.s1_f32 || a.s1_bf16) && (a.da_f32 || a.da_bf16) && (a.d1_f32 || a.d1_bf16), CTDD_EINVAL, "gn bwd: null tensor");
+  CTDD_REQUIRE(!(a.dsum_bn || a.dsum_n) || a.C2 == 0, CTDD_EINVAL, "gn bwd: per-sample sums of dX are for a single source");
   CTDD_REQUIRE(a.drop_p >= 0.0f && a.drop_p < 1.0f && (a.drop_p == 0.0f || a.rng), CTDD_EINVAL, "gn bwd: dropout p=%g", (double)a.drop_p);
+  const int vpp = C / 8, lanes = 256 / vpp;
+  // ~8 pixels per thread and pass: slices of 8 * lanes pixels, at most ~1024 workgroups
+  const int gx = max(1, min((a.HW + 8 * lanes - 1) / (8 * lanes), max(1, 1024 / max(a.B, 1))));
   hipStream_t st = (hipStream_t)stream;
-  const int gx = max(1, min(a.HW / 16, 256 * 4 / max(a.B, 1) + 1));
-  hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(gx, a.B), dim3(256), (size_t)4 * C * sizeof(float), st, a);
-  if (int rc = finish_launch("k_gn_bwd_reduce")) return rc;
-  const int64_t nv = (int64_t)a.HW * (C / 8);
-  const int ga = (int)max((int64_t)1, min((nv + 255) / 256, (int64_t)(2048 / max(a.B, 1) + 1)));
-  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(ga, a.B), dim3(256), (size_t)4 * C * sizeof(float), st, a);
-  return finish_launch("k_gn_bwd_apply");
+  hipLaunchKernelGGL(k_gn_bwd_sums, dim3(gx, a.B), dim3(256), (size_t)(8 * C + 256 * 16) * sizeof(float), st, a);
+  if (int rc = finish_launch("k_gn_bwd_sums")) return rc;
+  hipLaunchKernelGGL(k_gn_bwd_dx, dim3(gx, a.B), dim3(256), (size_t)(8 * C + 4 * C) * sizeof(float), st, a);
+  return finish_launch("k_gn_bwd_dx");
 }
 
 extern "C" int ctdd_unet_dropout(float* f32, void* bf16, int64_t n, float p, const uint64_t* rng, uint64_t layer, void* stream) {
@@ -737,8 +960,14 @@ extern "C" int ctdd_unet_colsum(const float* f32, const void* bf16, int B, int H
 
 extern "C" int ctdd_unet_sum_batch(const float* in, int B, int64_t bstride, int jstride, int n, float* out, int accumulate, void* stream) {
   CTDD_REQUIRE(in && out && n > 0 && B > 0, CTDD_EINVAL, "sum_batch: null / empty");
-  hipLaunchKernelGGL(k_sum_batch, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, B, bstride, jstride, n, out, accumulate);
+  hipLaunchKernelGGL(k_sum_batch, dim3((n + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, B, bstride, jstride, n, out, accumulate);
   return finish_launch("k_sum_batch");
+}
+
+extern "C" int ctdd_unet_sum_jobs(const void* jobs_dev, int njobs, void* stream) {
+  CTDD_REQUIRE(jobs_dev && njobs > 0, CTDD_EINVAL, "sum_jobs: empty table");
+  hipLaunchKernelGGL(k_sum_jobs, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const SumJob*)jobs_dev);
+  return finish_launch("k_sum_jobs");
 }
 
 extern "C" int ctdd_unet_accumulate(const float* src_f32, const void* src_bf16, float* dst_f32, void* dst_bf16, int64_t n, int accumulate,
@@ -782,14 +1011,22 @@ extern "C" int ctdd_unet_attention_bwd(const void* args_, void* stream) {
   return finish_launch("k_attn_small_bwd");
 }
 
+extern "C" int64_t ctdd_unet_first_conv_wgrad_scratch(int B, int H, int Cin, int Cout) {
+  return (int64_t)B * first_wgrad_bands(H) * Cout * (Cin * 9 + 1);
+}
 extern "C" int ctdd_unet_first_conv_wgrad(const void* args_, void* stream) {
   const FirstWgradArgs& a = *(const FirstWgradArgs*)args_;
-  CTDD_REQUIRE((a.x64 || a.x32) && (a.dy_f32 || a.dy_bf16) && a.gw, CTDD_EINVAL, "first conv wgrad: null operand");
+  CTDD_REQUIRE((a.x64 || a.x32) && (a.dy_f32 || a.dy_bf16) && a.gw && a.partial, CTDD_EINVAL, "first conv wgrad: null operand");
   CTDD_REQUIRE(a.Cin >= 1 && a.Cin <= 4 && a.Cout <= 256, CTDD_ERANGE, "first conv wgrad: Cin=%d Cout=%d", a.Cin, a.Cout);
-  const int HW = a.H * a.W;
-  const int gx = max(1, min(HW / 32, 512 / max(a.B, 1) + 1));
-  hipLaunchKernelGGL(k_first_conv_wgrad, dim3(gx, a.B), dim3(256), (size_t)a.Cout * (a.Cin * 9 + 1) * sizeof(float), (hipStream_t)stream, a);
-  return finish_launch("k_first_conv_wgrad");
+  const int gx = first_wgrad_bands(a.H), rows_per = (a.H + gx - 1) / gx, K = a.Cin * 9;
+  const size_t lds = ((size_t)a.Cin * (rows_per + 2) * (a.W + 2) + (size_t)a.Cout * (K + 1)) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_first_conv_wgrad, dim3(gx, a.B), dim3(256), lds, st, a);
+  if (int rc = finish_launch("k_first_conv_wgrad")) return rc;
+  const int64_t row = (int64_t)a.Cout * (K + 1);
+  hipLaunchKernelGGL(k_sum_batch, dim3((a.Cout * K + 63) / 64), dim3(256), 0, st, a.partial, gx * a.B, row, 1, a.Cout * K, a.gw, 0);
+  if (a.gbias) hipLaunchKernelGGL(k_sum_batch, dim3((a.Cout + 63) / 64), dim3(256), 0, st, a.partial + (size_t)a.Cout * K, gx * a.B, row, 1, a.Cout, a.gbias, 0);
+  return finish_launch("k_sum_batch");
 }
 
 extern "C" int ctdd_unet_pack_weights(const void* table_dev, int nent, int64_t total, int f32, uint64_t* rng_bump, void* stream) {

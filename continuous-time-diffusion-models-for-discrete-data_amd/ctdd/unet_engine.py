@@ -642,8 +642,9 @@ class UNetEngine:
             else:
                 tc = unet_train.TrainCtx(self, B, dropout)
                 st = self._build(B, x.dtype, tc=tc)
-                st.gen, st.busy, st.fgraph, st.bgraph, st.warm = 0, False, None, None, 0
+                st.gen, st.busy, st.fgraph, st.bgraph = 0, False, None, None
                 tc.rng[0] = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+                self._train_warm_and_capture(st, x, times)
                 pool.append(st)
         tc = st.tc
         Cin, H0, W0 = self.cfg.data.shape
@@ -658,13 +659,50 @@ class UNetEngine:
             return logits.reshape(B, Cin * H0 * W0, self.net.S)
         return out
 
+    def _run_bwd_plan(self, st):
+        tc = st.tc
+        tc.zbuf.zero_()
+        tc.bzpool.zero_()
+        tc.gflat.zero_()
+        for step in st.bwd_plan:
+            step()
+
+    def _train_warm_and_capture(self, st, x, times):
+        """Run both plans once eagerly (first launches set kernel attributes), then capture each as ONE HIP graph."""
+        with torch.no_grad():
+            st.x_in.copy_(x.reshape(st.x_in.shape))
+            st.t_in.copy_(times.float())
+            st.tc.tproj.copy_(self._time_projections(times, st.tc.resblocks))
+            self._run_plan(st)
+            self._run_bwd_plan(st)                  # (zero seed: only exercises the launches)
+            torch.cuda.synchronize()
+            if getattr(self.cfg.model, "engine_graph", True):
+                try:
+                    gf = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gf):
+                        self._run_plan(st)
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        self._run_bwd_plan(st)
+                    st.fgraph, st.bgraph = gf, gb
+                except native.CtddError:
+                    raise
+                except RuntimeError as e:
+                    import warnings
+                    warnings.warn(f"[ctdd] UNetEngine: HIP-graph capture of the training plans failed ({e}); eager launches", RuntimeWarning)
+                    st.fgraph = st.bgraph = None
+                    torch.cuda.synchronize()
+
     def _train_run_forward(self, st, x, times, tproj):
         st.gen = self.__dict__["_train_gen"] = self.__dict__.get("_train_gen", 0) + 1
         st.busy = True
         st.x_in.copy_(x.reshape(st.x_in.shape))
         st.t_in.copy_(times.float())
         st.tc.tproj.copy_(tproj.detach())
-        self._run_plan(st)
+        if st.fgraph is not None:
+            st.fgraph.replay()
+        else:
+            self._run_plan(st)
         out = st.net_out if self.cfg.model.model_output == "logistic_pars" else st.logits
         return out.clone()
 
@@ -684,11 +722,10 @@ class UNetEngine:
             S = self.net.S
             d = d.view(-1, Cin, H0 * W0, S).permute(0, 2, 1, 3)
         tc.seed_in.copy_(d.reshape(tc.seed_in.shape))
-        tc.zbuf.zero_()
-        tc.bzpool.zero_()
-        tc.gflat.zero_()
-        for step in st.bwd_plan:
-            step()
+        if st.bgraph is not None:
+            st.bgraph.replay()
+        else:
+            self._run_bwd_plan(st)
         st.busy = False
         grads = [tc.gflat[o:o + n].view(shape) for o, n, shape in (tc.grad_view[id(p)] for p in tc.engine_params)]
         return tc.dtproj.clone(), grads

@@ -21,7 +21,7 @@ import ctypes as C
 import torch
 
 from . import native
-from .unet_engine import SEG_1x1, SEG_3x3, SEG_3x3_S2, _ConvArgs, _lib, _Tensor
+from .unet_engine import SEG_1x1, SEG_3x3, SEG_3x3_S2, _lib
 
 SEG_3x3_S2T = 4
 WG_3x3, WG_1x1, WG_3x3_S2 = 0, 1, 2
@@ -30,14 +30,14 @@ _P, _I, _F, _I64, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
 
 class _WgradArgs(C.Structure):
     _fields_ = [("x", _P), ("dy", _P), ("gw", _P), ("B", _I), ("H", _I), ("W", _I), ("Hin", _I), ("Win", _I), ("N", _I), ("ldy", _I),
-                ("C", _I), ("Ktot", _I), ("koff", _I), ("kind", _I), ("nlr", _I), ("nwn", _I), ("nchunks", _I)]
+                ("C", _I), ("Ktot", _I), ("koff", _I), ("kind", _I), ("nlr", _I), ("nwn", _I), ("nchunks", _I), ("grid_x", _I), ("tap", _I)]
 
 
 class _GnBwdArgs(C.Structure):
     _fields_ = [("s1_f32", _P), ("s1_bf16", _P), ("st1", _P), ("C1", _I), ("s2_f32", _P), ("s2_bf16", _P), ("st2", _P), ("C2", _I),
                 ("gamma", _P), ("beta", _P), ("B", _I), ("HW", _I), ("G", _I), ("eps", _F), ("swish", _I), ("da_f32", _P), ("da_bf16", _P),
                 ("sums", _P), ("d1_f32", _P), ("d1_bf16", _P), ("acc1", _I), ("d2_f32", _P), ("d2_bf16", _P), ("acc2", _I),
-                ("drop_p", _F), ("rng", _P), ("layer", _U64)]
+                ("drop_p", _F), ("rng", _P), ("layer", _U64), ("dsum_bn", _P), ("dsum_stride", _I), ("dsum_n", _P)]
 
 
 class _AttnBwdArgs(C.Structure):
@@ -47,7 +47,11 @@ class _AttnBwdArgs(C.Structure):
 
 class _FirstWgradArgs(C.Structure):
     _fields_ = [("x64", _P), ("x32", _P), ("lo", _F), ("hi", _F), ("dy_f32", _P), ("dy_bf16", _P), ("B", _I), ("Cin", _I), ("H", _I),
-                ("W", _I), ("Cout", _I), ("gw", _P), ("gbias", _P)]
+                ("W", _I), ("Cout", _I), ("gw", _P), ("gbias", _P), ("partial", _P)]
+
+
+class _SumJob(C.Structure):
+    _fields_ = [("inp", _P), ("out", _P), ("bstride", _I64), ("B", _I), ("jstride", _I), ("n", _I), ("accumulate", _I), ("j0", _I), ("pad_", _I)]
 
 
 class _PackEntry(C.Structure):
@@ -55,9 +59,9 @@ class _PackEntry(C.Structure):
                 ("ntap", _I), ("Ktot", _I), ("koff", _I), ("flip", _I), ("ldd", _I), ("pad_", _I), ("first", _I64)]
 
 
-TRAIN_EXPORTS = ("ctdd_unet_wgrad", "ctdd_unet_gn_bwd", "ctdd_unet_dropout", "ctdd_unet_colsum", "ctdd_unet_sum_batch", "ctdd_unet_accumulate",
+TRAIN_EXPORTS = ("ctdd_unet_wgrad", "ctdd_unet_gn_bwd", "ctdd_unet_dropout", "ctdd_unet_colsum", "ctdd_unet_sum_batch", "ctdd_unet_sum_jobs", "ctdd_unet_accumulate",
                  "ctdd_unet_downsum2x", "ctdd_unet_upsample2x_f32", "ctdd_unet_cast_rows", "ctdd_unet_attention_bwd",
-                 "ctdd_unet_first_conv_wgrad", "ctdd_unet_pack_weights", "ctdd_unet_unpack_grads")
+                 "ctdd_unet_first_conv_wgrad", "ctdd_unet_first_conv_wgrad_scratch", "ctdd_unet_pack_weights", "ctdd_unet_unpack_grads")
 _sigs_done = False
 
 
@@ -65,10 +69,11 @@ def lib():
     global _sigs_done
     l = _lib()
     if not _sigs_done:
-        for name, argt in (("ctdd_unet_wgrad", [_P, _I, _I, _P]), ("ctdd_unet_gn_bwd", [_P, _P]),
+        for name, argt in (("ctdd_unet_wgrad", [_P, _P, _I, _I, _P]), ("ctdd_unet_gn_bwd", [_P, _P]),
                            ("ctdd_unet_dropout", [_P, _P, _I64, _F, _P, _U64, _P]),
                            ("ctdd_unet_colsum", [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
                            ("ctdd_unet_sum_batch", [_P, _I, _I64, _I, _I, _P, _I, _P]),
+                           ("ctdd_unet_sum_jobs", [_P, _I, _P]),
                            ("ctdd_unet_accumulate", [_P, _P, _P, _P, _I64, _I, _P]),
                            ("ctdd_unet_downsum2x", [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
                            ("ctdd_unet_upsample2x_f32", [_P, _I, _I, _I, _I, _P, _P]),
@@ -77,6 +82,7 @@ def lib():
                            ("ctdd_unet_pack_weights", [_P, _I, _I64, _I, _P, _P]), ("ctdd_unet_unpack_grads", [_P, _I, _I64, _P])):
             fn = getattr(l, name)
             fn.argtypes, fn.restype = argt, _I
+        l.ctdd_unet_first_conv_wgrad_scratch.argtypes, l.ctdd_unet_first_conv_wgrad_scratch.restype = [_I, _I, _I, _I], _I64
         _sigs_done = True
     return l
 
@@ -172,39 +178,91 @@ class TrainCtx:
             self._grads[k].B, self._grads[k].H, self._grads[k].W = t.B, t.H, t.W
         return self._grads[k]
 
-    def _wgrad_launch(self, launch, x_t, gy, N, ldy, Cseg, e, kind, B, H, W, Hin, Win):
-        eng, l = self.eng, lib()
-        a = _WgradArgs()
-        a.x = (x_t.f32 if eng.precise else x_t.hi).data_ptr()
-        a.dy = (gy.f32 if eng.precise else gy.hi).data_ptr()
-        a.gw = e["gw_ptr"]
-        a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff = B, H, W, Hin, Win, N, ldy, Cseg, e["Ktot"], e["koff"]
-        a.kind = {SEG_3x3: WG_3x3, SEG_1x1: WG_1x1, SEG_3x3_S2: WG_3x3_S2}[kind]
-        nwn = 1 if N <= 32 else (4 if Cseg <= 32 else 2)
-        nwc = 4 // nwn
-        tb = 128 if eng.precise else 64
-        budget = int(getattr(eng.cfg.model, "wgrad_lds_bytes", 72 * 1024))            # two workgroups per CU
-        if a.kind == WG_3x3:
-            Wp = W + 2
-            nlr = 1
-            while True:
-                KP = -(-((nlr + 1) * Wp) // 16) * 16
-                if (KP * nwn + (KP + 2 * Wp + 2) * nwc) * tb > budget or nlr + 1 > B * (H + 1):
-                    break
-                nlr += 1
-            nchunks = -(-(B * (H + 1)) // nlr)
-        else:
-            nlr = max(16, (budget // ((nwn + nwc) * tb)) // 16 * 16)
+    def wgrad_geometry(self, kind, B, H, W, N, Cseg):
+        """(nwn, nlr, nchunks) of one weight-gradient table entry: wave arrangement and chunk size within the kernel's LDS
+        (one workgroup per CU) and staging-slot limits (8 + 10 sixteen-byte vectors per thread)."""
+        eng = self.eng
+        tb, epv = (128, 4) if eng.precise else (64, 8)
+        budget = int(getattr(eng.cfg.model, "wgrad_lds_bytes", 144 * 1024))
+        prefer = [1, 2, 4] if N <= 32 else ([4, 2, 1] if Cseg <= 32 else [2, 4, 1])
+        for nwn in prefer:                                 # first arrangement whose smallest chunk fits the staging slots
+            nwc = 4 // nwn
+            vn, vc = 32 * nwn // epv, 32 * nwc // epv
+            if kind == WG_3x3:
+                Wp = W + 2
+
+                def fits(n_):
+                    KP = -(-(n_ * Wp) // 16) * 16
+                    return ((KP * nwn + (KP + 2 * Wp + 2) * nwc) * tb <= budget and n_ * W * vn <= 2048 and (n_ + 2) * W * vc <= 2560)
+                if not fits(1):
+                    continue
+                nlr = 1
+                while fits(nlr + 1) and nlr + 1 <= B * (H + 1):
+                    nlr += 1
+                return nwn, nlr, -(-(B * (H + 1)) // nlr)
+            nlr = min(budget // ((nwn + nwc) * tb), 2048 // vn, 2560 // vc) // 16 * 16
+            if nlr < 16:
+                continue
             nlr = min(nlr, -(-(B * H * W) // 16) * 16)
-            nchunks = -(-(B * H * W) // nlr)
-        a.nlr, a.nwn, a.nchunks = nlr, nwn, nchunks
-        groups = -(-N // (32 * nwn)) * -(-Cseg // (32 * nwc)) * (9 if a.kind == WG_3x3_S2 else 1)
-        target = int(getattr(eng.cfg.model, "wgrad_workgroups", 512))
-        grid_x = max(1, min(nchunks, target // groups))
-        self.keep.append(a)
-        ntap = 1 if kind == SEG_1x1 else 9
-        launch(l.ctdd_unet_wgrad, C.byref(a), int(eng.precise), grid_x, label=f"wgrad {H}x{W} N={N} C={Cseg} kind={a.kind} nlr={nlr} grid={grid_x}x{groups}",
-               flops=2 * B * H * W * N * Cseg * ntap)
+            return nwn, nlr, -(-(B * H * W) // nlr)
+        raise native.CtddError(f"weight gradient: no chunk of a {H}x{W} grid fits the kernel's staging slots")
+
+    def _wgrad_entry(self, x_t, gy, N, ldy, Cseg, e, kind, B, H, W, Hin, Win):
+        """Queue the weight gradient of one K-segment; all of them run as ONE table launch at the end of the backward plan."""
+        eng = self.eng
+        wk = {SEG_3x3: WG_3x3, SEG_1x1: WG_1x1, SEG_3x3_S2: WG_3x3_S2}[kind]
+        nwn, nlr, nchunks = self.wgrad_geometry(wk, B, H, W, N, Cseg)
+        for tap in (range(9) if wk == WG_3x3_S2 else (0,)):
+            a = _WgradArgs()
+            a.x = (x_t.f32 if eng.precise else x_t.hi).data_ptr()
+            a.dy = (gy.f32 if eng.precise else gy.hi).data_ptr()
+            a.gw = e["gw_ptr"]
+            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff = B, H, W, Hin, Win, N, ldy, Cseg, e["Ktot"], e["koff"]
+            a.kind, a.nlr, a.nwn, a.nchunks, a.tap = wk, nlr, nwn, nchunks, tap
+            self.wgrad_entries.append(a)
+
+    @staticmethod
+    def _sum_jobs_table(jobs, dev):
+        """(in, B, bstride, jstride, n, out, accumulate) reductions -> device table of 64-output jobs for ctdd_unet_sum_jobs."""
+        rows = []
+        for inp, Bn, bstride, jstride, n, out, acc in jobs:
+            for j0 in range(0, n, 64):
+                rows.append(_SumJob(inp, out, bstride, Bn, jstride, n, acc, j0, 0))
+        tab = (_SumJob * len(rows))(*rows)
+        return torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev), len(rows)
+
+    def _wgrad_table_launch(self, launch):
+        """One ctdd_unet_wgrad launch for every queued entry.  M-split per entry: every workgroup gets about the same number
+        of (16-pixel step x tap) units, ~`wgrad_wgs_per_cu` workgroups per CU over the whole table -- few enough that the
+        float atomics the M-split workgroups meet in stay far below the matrix time."""
+        eng, l = self.eng, lib()
+        self.wgrad_tabs = []
+        for nine in (True, False):                     # nine-tap (stride-1 3x3) entries and one-tap entries: one launch each
+            ents = [a for a in self.wgrad_entries if (a.kind == WG_3x3) == nine]
+            if ents:
+                self._wgrad_launch_table(launch, ents)
+
+    def _wgrad_launch_table(self, launch, ents):
+        eng, l = self.eng, lib()
+        cost, groups = [], []
+        for a in ents:
+            nwc = 4 // a.nwn
+            KP = -(-(a.nlr * (a.W + 2)) // 16) * 16 if a.kind == WG_3x3 else a.nlr
+            # per chunk: (16-pixel steps x taps) matrix instructions per wave + a fixed staging / barrier share (~48 of them)
+            cost.append(a.nchunks * ((KP // 16) * (9 if a.kind == WG_3x3 else 1) + int(getattr(eng.cfg.model, "wgrad_chunk_overhead", 48))))
+            groups.append(-(-a.N // (32 * a.nwn)) * -(-a.C // (32 * nwc)))
+        total = sum(c * g for c, g in zip(cost, groups))
+        target = max(1, total // (256 * int(getattr(eng.cfg.model, "wgrad_wgs_per_cu", 3))))
+        flops = 0
+        for a, c in zip(ents, cost):
+            a.grid_x = max(1, min(a.nchunks, -(-c // target)))
+            flops += 2 * a.B * a.H * a.W * a.N * a.C * (9 if a.kind == WG_3x3 else 1)
+        tab = (_WgradArgs * len(ents))(*ents)
+        dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.dev)
+        self.wgrad_tabs.append((tab, dev_tab))
+        nwg = sum(a.grid_x * g for a, g in zip(ents, groups))
+        launch(l.ctdd_unet_wgrad, dev_tab.data_ptr(), C.addressof(tab), len(ents), int(eng.precise),
+               label=f"wgrad table: {len(ents)} entries ({'3x3' if ents[0].kind == WG_3x3 else '1x1 / stride-2 taps / bias'}), {nwg} workgroups", flops=flops)
 
     def finish(self, st, eng):
         """Lay out the backward plan (called by UNetEngine._build before its pools are resolved)."""
@@ -233,7 +291,7 @@ class TrainCtx:
             if kind == "gn":
                 need += B * sum(s_.C for s_ in r["srcs"]) * 2 + 4
             elif kind == "conv":
-                need += -(-r["N"] // 8) * 8 + 4
+                need += r["N"] * 8 + 4
         self.zbuf = torch.zeros(need, dtype=torch.float32, device=dev)
         zbase, zcur = self.zbuf.data_ptr(), 0
 
@@ -251,6 +309,13 @@ class TrainCtx:
 
         # ---- backward plan
         bwd, bzero = [], []
+        self.wgrad_entries, sum_jobs = [], []
+        ones = type("Ones", (), {})()                  # all-ones "activations" [B*H0*W0][8]: bias gradients as weight gradients
+        dt = torch.float32 if eng.precise else torch.bfloat16
+        Cin0, H0_, W0_ = eng.cfg.data.shape
+        ones_t = torch.ones((B * H0_ * W0_, 8), dtype=dt, device=dev)
+        ones.f32, ones.hi = (ones_t, None) if eng.precise else (None, ones_t)
+        self.keep.append(ones_t)
         st.cur_lists["plan"], st.cur_lists["zero"] = bwd, bzero
         # seed: gradient of the network output (logits (B, D, S) fp32 or net_out [B*HW][2C] fp32) -> the mode's operand type
         last = self.records[-1][1]
@@ -269,6 +334,7 @@ class TrainCtx:
             t.hi, t.f32, t.C, t.stats = g_.hi, g_.f32, Cn, None
             return t
 
+        tb_conv_of = {id(r["out"]): r for kind, r in self.records if kind == "conv" and r["tb"] is not None and r["out"] is not None}
         for kind, r in reversed(self.records):
             if kind == "conv":
                 gy = self.g(r["out"]) if r["out"] is not None else out_grads[id(r["out_f32"])]
@@ -280,19 +346,20 @@ class TrainCtx:
                 gyT = as_seg(gy, ldy)
                 # bias gradients (+ the per-sample time-projection gradient): per-(sample, channel) sums of the output gradient
                 bps = r["bias_params"]
-                if bps or r["tb"] is not None:
+                if (bps or r["tb"] is not None) and not r.get("sums_done"):
                     out_bn, stride = None, 0
                     if r["tb"] is not None:
                         out_bn, stride = dtproj_ptr + (r["tb"][0] - self.tproj.data_ptr()), r["tb"][1]
-                    n8 = -(-N // 8) * 8
-                    direct = bool(bps) and n8 == N
-                    tmp = None if (direct or not bps) else zalloc(n8)
-                    launch(l.ctdd_unet_colsum, ptr(gy.f32), ptr(gy.hi), B, Ho * Wo, n8, ldy, out_bn, stride,
-                           gptr(bps[0]) if direct else tmp, label="bias / time-projection gradient")
-                    if tmp is not None:
-                        launch(l.ctdd_unet_sum_batch, tmp, 1, 0, 1, N, gptr(bps[0]), 0, label="bias gradient (unpadded)")
-                    for extra in bps[1:]:
-                        launch(l.ctdd_unet_sum_batch, gptr(bps[0]), 1, 0, 1, N, gptr(extra), 0, label="bias gradient copy")
+                    if out_bn is not None:            # (a time-projection gradient the GroupNorm backward could not give)
+                        launch(l.ctdd_unet_colsum, ptr(gy.f32), ptr(gy.hi), B, Ho * Wo, -(-N // 8) * 8, ldy, out_bn, stride, None,
+                               label="time-projection gradient")
+                    if bps:
+                        # sum over all pixels of gy = a weight gradient against an all-ones input: one more entry of the
+                        # weight-gradient table (kind 1x1, eight identical columns), column 0 copied out by the sums launch
+                        scr = zalloc(N * 8)
+                        self._wgrad_entry(ones, gy, N, ldy, 8, dict(gw_ptr=scr, Ktot=8, koff=0), SEG_1x1, B, Ho, Wo, Ho, Wo)
+                        for bp in bps:
+                            sum_jobs.append((scr, 1, 0, 8, N, gptr(bp), 0))
                 # identity skip / residual
                 if r["res"] is not None:
                     gr = self.g(r["res"])
@@ -301,7 +368,7 @@ class TrainCtx:
                     gr.has = True
                 for (src, cs, skind), e in zip(r["segs"], r["per_seg"]):
                     one = skind == SEG_1x1
-                    self._wgrad_launch(launch, src, gy, N, ldy, cs, e, skind, B, Ho, Wo, Ho if one else Hi, Wo if one else Wi)
+                    self._wgrad_entry(src, gy, N, ldy, cs, e, skind, B, Ho, Wo, Ho if one else Hi, Wo if one else Wi)
                     # data gradient of the segment: a convolution of gy with the flipped / transposed weights
                     gs = self.g(src)
                     packed = (None, e["dgrad"]) if eng.precise else (e["dgrad"], None)
@@ -337,10 +404,18 @@ class TrainCtx:
                 a.drop_p, a.rng, a.layer = float(r["drop_p"]), self.rng.data_ptr(), r["layer"]
                 sums = zalloc(B * Ct * 2)
                 a.sums = sums
+                cr = tb_conv_of.get(id(s1)) if len(srcs) == 1 else None
+                if cr is not None and len(cr["bias_params"]) == 1:
+                    # the GroupNorm input is conv1's output + bias + time projection and has no other consumer: sum_p dX per
+                    # (sample, channel) IS the time-projection gradient, its sum over samples the bias gradient (closed form
+                    # from the sums: no pass over the gradient tensor)
+                    a.dsum_bn, a.dsum_stride = dtproj_ptr + (cr["tb"][0] - self.tproj.data_ptr()), cr["tb"][1]
+                    a.dsum_n = gptr(cr["bias_params"][0])
+                    cr["sums_done"] = True
                 self.keep.append(a)
                 launch(l.ctdd_unet_gn_bwd, C.byref(a), label=f"gn bwd C={Ct}")
-                launch(l.ctdd_unet_sum_batch, sums, B, 2 * Ct, 2, Ct, gptr(norm.bias), 0, label="gn dbeta")
-                launch(l.ctdd_unet_sum_batch, sums + 4, B, 2 * Ct, 2, Ct, gptr(norm.weight), 0, label="gn dgamma")
+                sum_jobs.append((sums, B, 2 * Ct, 2, Ct, gptr(norm.bias), 0))
+                sum_jobs.append((sums + 4, B, 2 * Ct, 2, Ct, gptr(norm.weight), 0))
             elif kind == "attn":
                 gao = self.g(r["ao"])
                 T, Cx = r["T"], r["Cx"]
@@ -367,7 +442,9 @@ class TrainCtx:
                 a.dy_f32, a.dy_bf16 = ptr(go.f32), ptr(go.hi)
                 a.B, a.Cin, a.H, a.W, a.Cout = fa.B, fa.Cin, fa.H, fa.W, fa.Cout
                 a.gw, a.gbias = gptr(c0.weight), gptr(c0.bias)
-                self.keep.append(a)
+                scratch = torch.zeros(int(l.ctdd_unet_first_conv_wgrad_scratch(fa.B, fa.H, fa.Cin, fa.Cout)), dtype=torch.float32, device=dev)
+                a.partial = scratch.data_ptr()
+                self.keep.extend([a, scratch])
                 launch(l.ctdd_unet_first_conv_wgrad, C.byref(a), label="first conv wgrad")
 
         # ---- split-K partial-sum buffers of the backward convolutions: their own pool, zeroed with the arena
@@ -389,15 +466,22 @@ class TrainCtx:
             first += e["N"] * e["C"] * e["ntap"]
         self.pack_total = first
         self.pack_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+        self._wgrad_table_launch(launch)               # every convolution's weight (and bias) gradient: one launch
+        self.bwd_sum_tab, nj = self._sum_jobs_table(sum_jobs, dev)
+        launch(l.ctdd_unet_sum_jobs, self.bwd_sum_tab.data_ptr(), nj, label=f"small sums: {len(sum_jobs)} reductions")
         launch(l.ctdd_unet_unpack_grads, self.pack_tab.data_ptr(), len(self.entries), self.pack_total, label="unpack gradients")
         # ---- forward prologue: ONE pack launch for every convolution weight (+ dropout step bump), folded biases
         pro = []
         st.cur_lists["plan"] = pro
         launch(l.ctdd_unet_pack_weights, self.pack_tab.data_ptr(), len(self.entries), self.pack_total, int(eng.precise),
                self.rng.data_ptr() if self.dropout else None, label="pack weights")
-        for buf, ps in self.bias_jobs:
-            for j, p in enumerate(ps):
-                launch(l.ctdd_unet_sum_batch, p.data_ptr(), 1, 0, 1, p.numel(), buf.data_ptr(), int(j > 0), label="folded bias")
+        if self.bias_jobs:                             # folded biases b = sum of parameters: the "batch" walks the parameters
+            jobs = []
+            for buf, ps in self.bias_jobs:
+                assert len(ps) == 2 and (ps[1].data_ptr() - ps[0].data_ptr()) % 4 == 0
+                jobs.append((ps[0].data_ptr(), 2, (ps[1].data_ptr() - ps[0].data_ptr()) // 4, 1, ps[0].numel(), buf.data_ptr(), 0))
+            self.fwd_sum_tab, nj = self._sum_jobs_table(jobs, dev)
+            launch(l.ctdd_unet_sum_jobs, self.fwd_sum_tab.data_ptr(), nj, label="folded biases")
         fwd_plan[:0] = pro
         st.cur_lists["plan"], st.cur_lists["zero"] = fwd_plan, st.zero_views_fwd
         st.bwd_plan, st.tc = bwd, self

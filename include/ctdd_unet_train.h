@@ -34,12 +34,17 @@ typedef struct {
   int nlr;            /* CTDD_WG_3x3: extended image rows per chunk; otherwise pixels per chunk (multiple of 16) */
   int nwn;            /* waves along N: 1, 2 or 4 (4 / nwn along C)                               */
   int nchunks;        /* CTDD_WG_3x3: ceil(B (H+1) / nlr); otherwise ceil(B H W / nlr)            */
+  int grid_x;         /* workgroups that share the chunks of this entry (M-split)                 */
+  int tap;            /* CTDD_WG_3x3_S2: the tap (0..8) this entry computes: nine entries per such convolution */
 } ctdd_wgrad_args;
-int ctdd_unet_wgrad(const void* wgrad_args, int f32, int grid_x, void* stream);
+/* ONE launch for a table of n entries (blockIdx.z = entry): the backward plan defers all weight gradients to its end so
+ * that equal-shaped convolutions fill the chip together with few M-split workgroups each (those meet in float atomics).
+ * table_dev: the entries in device memory; table_host: the same entries in host memory (validated, sized from). */
+int ctdd_unet_wgrad(const void* table_dev, const void* table_host, int n, int f32, void* stream);
 
-/* GroupNorm (+Swish, +Dropout) backward over the channel concatenation of one or two tensors (unet.py:103-133):
- * two launches -- per-(sample, channel) sums of dz and dz*xhat into `sums` (zeroed by the caller), then
- * dX into d1 / d2 (acc != 0: added to what is there).  dgamma / dbeta = ctdd_unet_sum_batch over `sums`. */
+/* GroupNorm (+Swish, +Dropout) backward over the channel concatenation of one or two tensors (unet.py:103-133): two
+ * launches over (sample, pixel slice) workgroups -- per-(sample, channel) sums of dz and dz*xhat into `sums` (zeroed by
+ * the caller), then dX into d1 / d2 (acc != 0: added to what is there).  dgamma / dbeta = sums over the samples of `sums`. */
 typedef struct {
   const float* s1_f32; const void* s1_bf16; const double* st1; int C1;   /* forward inputs + their [B][C][2] fp64 statistics */
   const float* s2_f32; const void* s2_bf16; const double* st2; int C2;
@@ -51,6 +56,8 @@ typedef struct {
   float* d2_f32; void* d2_bf16; int acc2;
   float drop_p; const uint64_t* rng; uint64_t layer;                      /* dropout applied after the activation (0: none); rng = device
                                                                              {seed, step}: the mask of element e is Philox(seed, step*4096 + layer, e) */
+  float* dsum_bn; int dsum_stride; float* dsum_n;                         /* optional, single source: sum_p dX[b,p,c] -> dsum_bn[b*stride + c] and
+                                                                             += into dsum_n[c]: the time-projection / conv1-bias gradients (unet.py:110,131) */
 } ctdd_gn_bwd_args;
 int ctdd_unet_gn_bwd(const void* gn_bwd_args, void* stream);
 /* the forward side of that dropout, in place on the activated tensor: a *= keep / (1 - p); same mask rule */
@@ -61,6 +68,9 @@ int ctdd_unet_colsum(const float* g_f32, const void* g_bf16, int B, int HW, int 
                      void* stream);
 /* out[j] (+)= sum_b in[b*bstride + j*jstride] */
 int ctdd_unet_sum_batch(const float* in, int B, int64_t bstride, int jstride, int n, float* out, int accumulate, void* stream);
+/* the same for a table of jobs in ONE launch: job = outputs j0 .. j0+63 of out[j] (+)= sum_b in[b*bstride + j*jstride], j < n */
+typedef struct { const float* in; float* out; int64_t bstride; int B, jstride, n, accumulate, j0, pad_; } ctdd_sum_job;
+int ctdd_unet_sum_jobs(const void* jobs_dev, int njobs, void* stream);
 /* dst (+)= src, n elements (n % 8 == 0): identity-skip / residual branch of a gradient */
 int ctdd_unet_accumulate(const float* src_f32, const void* src_bf16, float* dst_f32, void* dst_bf16, int64_t n, int accumulate, void* stream);
 /* backward of nearest-2x upsampling (unet.py:79-85): out[b,y,x,c] (+)= sum of the 2x2 block of up */
@@ -76,7 +86,9 @@ int ctdd_unet_attention_bwd(const void* attn_bwd_args, void* stream);
 
 /* weight (torch layout [Cout][Cin][3][3]) and bias gradient of the first conv on the centred integer state (unet.py:343) */
 typedef struct { const int64_t* x64; const int32_t* x32; float lo, hi; const float* dy_f32; const void* dy_bf16;
-                 int B, Cin, H, W, Cout; float* gw; float* gbias; } ctdd_first_wgrad_args;
+                 int B, Cin, H, W, Cout; float* gw; float* gbias;
+                 float* partial;   /* scratch of ctdd_unet_first_conv_wgrad_scratch(B, H, Cin, Cout) floats */ } ctdd_first_wgrad_args;
+int64_t ctdd_unet_first_conv_wgrad_scratch(int B, int H, int Cin, int Cout);
 int ctdd_unet_first_conv_wgrad(const void* first_wgrad_args, void* stream);
 
 /* One table for all convolution weights of a network: torch parameter -> forward layout [N][Ktot] and data-gradient

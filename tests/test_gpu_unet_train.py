@@ -24,22 +24,22 @@ def _check(rc, lib):
 
 
 # ---------------------------------------------------------------------------------------------- weight gradient
-@pytest.mark.parametrize("f32", [False, True])
-@pytest.mark.parametrize("B,H,W,Cc,N,kind,nwn", [
-    (3, 28, 28, 96, 96, 0, 2),        # MNIST level-0 shape; chunks straddle images
-    (5, 14, 14, 192, 96, 0, 2),
-    (4, 7, 7, 64, 192, 0, 2),         # several images per chunk (zero rows between them)
-    (2, 8, 8, 16, 32, 0, 1),          # golden tiny net: one n tile
-    (2, 8, 8, 32, 256, 0, 4),         # C <= 32
-    (3, 14, 14, 96, 192, 1, 2),       # linear skip (1x1)
-    (2, 7, 7, 192, 576, 1, 2),        # attention qkv
-    (3, 14, 14, 96, 96, 2, 2),        # Downsample: stride 2 from 28x28
-    (2, 3, 3, 32, 32, 2, 2),          # stride 2 from an odd 7x7 grid
-])
-def test_wgrad_kernel(B, H, W, Cc, N, kind, nwn, f32):
+WGRAD_CASES = [
+    (3, 28, 28, 96, 96, 0, 2, 5, 7),      # MNIST level-0 shape; chunks straddle images
+    (5, 14, 14, 192, 96, 0, 2, 5, 3),
+    (4, 7, 7, 64, 192, 0, 2, 11, 2),      # several images per chunk (zero rows between them)
+    (2, 8, 8, 16, 32, 0, 1, 11, 1),       # golden tiny net: one n tile
+    (2, 8, 8, 32, 256, 0, 4, 11, 2),      # C <= 32
+    (3, 14, 14, 96, 192, 1, 2, 112, 4),   # linear skip (1x1)
+    (2, 7, 7, 192, 576, 1, 2, 64, 1),     # attention qkv
+    (3, 14, 14, 96, 96, 2, 2, 112, 3),    # Downsample: stride 2 from 28x28
+    (2, 3, 3, 32, 32, 2, 2, 16, 1),       # stride 2 from an odd 7x7 grid
+]
+
+
+def _wgrad_case(case, f32, g):
     from ctdd import unet_train as ut
-    lib = ut.lib()
-    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + kind)
+    B, H, W, Cc, N, kind, nwn, nlr, gx = case
     Hin, Win = (H, W) if kind != 2 else (2 * H + (1 if H == 3 else 0), 2 * W + (1 if W == 3 else 0))
     dt = torch.float32 if f32 else torch.bfloat16
     x = torch.randn((B, Hin, Win, Cc), generator=g, device="cuda").to(dt)
@@ -47,31 +47,49 @@ def test_wgrad_kernel(B, H, W, Cc, N, kind, nwn, f32):
     ntap = 1 if kind == 1 else 9
     koff, Ktot = 16, 16 + ntap * Cc + 8                        # the segment sits inside a wider packed matrix
     gw = torch.zeros((N, Ktot), dtype=torch.float32, device="cuda")
-    a = ut._WgradArgs()
-    a.x, a.dy, a.gw = x.data_ptr(), dy.data_ptr(), gw.data_ptr()
-    a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind, a.nwn = B, H, W, Hin, Win, N, N, Cc, Ktot, koff, kind, nwn
-    if kind == 0:
-        a.nlr = 5 if H >= 14 else 11
-        a.nchunks = -(-(B * (H + 1)) // a.nlr)
-    else:
-        a.nlr = 112
-        a.nchunks = -(-(B * H * W) // a.nlr)
-    _check(lib.ctdd_unet_wgrad(C.byref(a), int(f32), 7, _stream()), lib)
-    torch.cuda.synchronize()
+    ents = []
+    for tap in (range(9) if kind == 2 else (0,)):
+        a = ut._WgradArgs()
+        a.x, a.dy, a.gw = x.data_ptr(), dy.data_ptr(), gw.data_ptr()
+        a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind, a.nwn = B, H, W, Hin, Win, N, N, Cc, Ktot, koff, kind, nwn
+        epv = 4 if f32 else 8                                  # staging-slot limits: 8 + 10 sixteen-byte vectors per thread
+        vn, vc = 32 * nwn // epv, 32 * (4 // nwn) // epv
+        if kind == 0:
+            a.nlr = max(1, min(nlr, 2048 // (W * vn), 2560 // (W * vc) - 2))
+        else:
+            a.nlr = max(16, min(nlr, 2048 // vn, 2560 // vc) // 16 * 16)
+        a.nchunks = -(-(B * (H + 1)) // a.nlr) if kind == 0 else -(-(B * H * W) // a.nlr)
+        a.grid_x, a.tap = min(gx, a.nchunks), tap
+        ents.append(a)
     # reference: autograd of the convolution on the same (rounded) operands
     w = torch.zeros((N, Cc, 3 if kind != 1 else 1, 3 if kind != 1 else 1), device="cuda", requires_grad=True)
     xin = x.float().permute(0, 3, 1, 2)
-    if kind == 2:
-        out = F.conv2d(F.pad(xin, [0, 1, 0, 1]), w, stride=2)
-    else:
-        out = F.conv2d(xin, w, padding=1 if kind == 0 else 0)
+    out = F.conv2d(F.pad(xin, [0, 1, 0, 1]), w, stride=2) if kind == 2 else F.conv2d(xin, w, padding=1 if kind == 0 else 0)
     assert out.shape[2:] == (H, W)
     out.backward(dy.float().permute(0, 3, 1, 2))
     ref = w.grad.permute(0, 2, 3, 1).reshape(N, ntap * Cc)       # [n][tap][c]
-    got = gw[:, koff:koff + ntap * Cc]
-    scale = ref.abs().max().item()
-    assert (got - ref).abs().max().item() < (2e-5 if f32 else 2e-5) * scale + 1e-6, ((got - ref).abs().max().item(), scale)
-    assert gw[:, :koff].abs().max().item() == 0 and gw[:, koff + ntap * Cc:].abs().max().item() == 0
+    return ents, (x, dy), gw, ref, (koff, ntap * Cc)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_wgrad_kernel(f32):
+    """ctdd_unet_wgrad: ONE launch over a table of segments (every kind, ragged chunk ends, several images per chunk, a
+    segment inside a wider packed matrix) against autograd's convolution weight gradients."""
+    from ctdd import unet_train as ut
+    lib = ut.lib()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    cases = [_wgrad_case(c, f32, g) for c in WGRAD_CASES]
+    for nine in (True, False):                      # a table holds nine-tap (3x3) entries or one-tap entries
+        ents = [a for c in cases for a in c[0] if (a.kind == 0) == nine]
+        tab = (ut._WgradArgs * len(ents))(*ents)
+        dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+        _check(lib.ctdd_unet_wgrad(dev_tab.data_ptr(), C.addressof(tab), len(ents), int(f32), _stream()), lib)
+    torch.cuda.synchronize()
+    for case, (_, _, gw, ref, (koff, width)) in zip(WGRAD_CASES, cases):
+        got = gw[:, koff:koff + width]
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() < 2e-5 * scale + 1e-6, (case, (got - ref).abs().max().item(), scale)
+        assert gw[:, :koff].abs().max().item() == 0 and gw[:, koff + width:].abs().max().item() == 0
 
 
 # ---------------------------------------------------------------------------------------------- transposed stride-2 conv
@@ -135,6 +153,10 @@ def test_groupnorm_backward(C1, C2, swish, f32):
     a.st1, a.C1, a.st2, a.C2 = st1.data_ptr(), C1, st2.data_ptr() if C2 else None, C2
     a.gamma, a.beta, a.B, a.HW, a.G, a.eps, a.swish = gamma.data_ptr(), beta.data_ptr(), B, HW, G, 1e-6, int(swish)
     a.sums, a.acc1, a.acc2, a.drop_p = sums.data_ptr(), 1, 0, 0.0
+    dsum_bn = torch.zeros((B, C1 + 5), device="cuda")
+    dsum_n = torch.zeros(C1, device="cuda")
+    if C2 == 0:                                   # single source: per-(sample, channel) sums of dX in closed form
+        a.dsum_bn, a.dsum_stride, a.dsum_n = dsum_bn.data_ptr(), C1 + 5, dsum_n.data_ptr()
     _check(lib.ctdd_unet_gn_bwd(C.byref(a), _stream()), lib)
     torch.cuda.synchronize()
     xr = xs.clone().requires_grad_(True)
@@ -146,6 +168,11 @@ def test_groupnorm_backward(C1, C2, swish, f32):
     tol = 2e-5 if f32 else 1.5e-2
     ref1 = xr.grad[..., :C1] + old1.float()
     assert (d1.float() - ref1).abs().max().item() < tol * ref1.abs().max().item()
+    if C2 == 0:
+        want = xr.grad.sum(1)
+        assert (dsum_bn[:, :C1] - want).abs().max().item() < 3e-4 * xr.grad.abs().sum(1).max().item()
+        assert (dsum_n - want.sum(0)).abs().max().item() < 3e-4 * xr.grad.abs().sum((0, 1)).max().item()
+        assert dsum_bn[:, C1:].abs().max().item() == 0
     if C2:
         assert (d2.float() - xr.grad[..., C1:]).abs().max().item() < tol * xr.grad.abs().max().item()
     np.testing.assert_allclose(sums[..., 0].sum(0).cpu().numpy(), br.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * br.grad.abs().max().item())
@@ -316,7 +343,7 @@ def test_train_step_through_the_engine_matches_torch_step():
     from config.mnist_config.config_tauUnet_mnist import get_config
     cfg = get_config()
     cfg.model.dropout, cfg.model.engine_precision = 0.0, "fp32"
-    cfg.model.update(ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16])
+    cfg.model.update(ch=32, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[48])
     torch.manual_seed(0)
     model = mu.create_model(cfg, torch.device("cuda"))
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -343,5 +370,10 @@ def test_train_step_through_the_engine_matches_torch_step():
         outs.append(ls)
     assert getattr(model._engine, "_train_plans", None) and ref._engine is None
     np.testing.assert_allclose(outs[0], outs[1], rtol=2e-4)
+    lr = cfg.optimizer.lr
     for (n, a), b in zip(model.named_parameters(), ref.parameters()):
-        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5, msg=lambda m, n=n: f"{n}: {m}")
+        # Adam's first steps move every weight by ~lr whatever the gradient's size: an entry whose gradient is rounding noise
+        # can take the other sign, so isolated differences up to 2 steps x lr are allowed, everything else agrees closely
+        d = (a - b).abs()
+        assert d.max().item() <= 2.2 * 2 * lr, (n, d.max().item())
+        assert (d > 2e-5 + 1e-3 * b.abs()).float().mean().item() < 2e-3, (n, (d > 2e-5 + 1e-3 * b.abs()).float().mean().item())
