@@ -144,6 +144,15 @@ class ImageX0PredBasePaul(nn.Module):
         if self._engine is None:
             self._engine = unet_engine.UNetEngine(self)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            if isinstance(self.net, DDP):
+                # through DDP.forward (reducer bookkeeping for this iteration); the wrapped U-Net hands over to the training plan,
+                # whose autograd Function returns every parameter gradient -> DDP's hooks bucket and all-reduce them (RCCL)
+                inner = unwrap(self.net)
+                inner._engine_hook = self._engine.train_forward
+                try:
+                    return self.net(x, times)
+                finally:
+                    inner._engine_hook = None
             return self._engine.train_forward(x, times)
         out = self._engine(x, times)
         # the plan owns its output buffer: hand out a copy unless the caller (a sampler loop that consumes the

@@ -174,6 +174,11 @@ class UNet(nn.Module):
         self.D = img_size * img_size
 
     def forward(self, x, t):
+        hook = getattr(self, "_engine_hook", None)
+        if hook is not None:
+            # cfg.distributed: the model wrapper calls this module through DistributedDataParallel.forward (so that the
+            # reducer expects this iteration's gradients) and the hand-written training plan takes over from here
+            return hook(x, t)
         temb = self.time(t)
         B, C, H, W = x.shape
         h = x0 = network_utils.center_data(x, self.x_min_max)

@@ -38,6 +38,7 @@ def _run(rank, world, port, q):
         torch.manual_seed(1000 * it + rank)
         last = step.step(state, loss, mb)
         state["n_iter"] += 1
+    assert getattr(model._engine, "_train_plans", None), "the HIP training plan did not run under DistributedDataParallel"
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double().cpu()
     ema = torch.cat([p.detach().reshape(-1) for p in model.shadow_params]).double().cpu()
     q.put((rank, float(last), flat[::97].numpy(), float(flat.abs().sum()), float(ema.abs().sum())))
