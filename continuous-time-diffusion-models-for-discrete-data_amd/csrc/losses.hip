@@ -21,6 +21,8 @@ struct CrmArgs {
   int64_t rows; int D, S, loss_type;
   float scale, nll_scale;
   float* grad; double* row_loss;
+  int ll_in;     // `logits` already holds ll_all = log p_t(. | x^{\d}) (reverse_prob / reverse_logscale logit types, from
+                 // ctdd_logprob): no log-softmax, grad = d loss / d ll_all (ctdd_logprob_bwd chains it to the logits)
 };
 
 __device__ inline float lwave_sum(float v) {
@@ -49,12 +51,15 @@ __global__ __launch_bounds__(256) void k_crm_rows(const CrmArgs a) {
   float* gr = a.grad + (size_t)row * S;
   const int x = min(max(a.xt[row], 0), S - 1);
   const int x0 = a.x0 ? min(max(a.x0[row], 0), S - 1) : -1;
-  float m = -INFINITY;
-  for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
-  m = lwave_max(m);
-  float z = 0.0f;
-  for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
-  const float L = m + logf(lwave_sum(z));
+  float L = 0.0f;
+  if (!a.ll_in) {
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
+    m = lwave_max(m);
+    float z = 0.0f;
+    for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
+    L = m + logf(lwave_sum(z));
+  }
   const float llx = l[x] - L;
   // pass 3: row loss and sum_s g[s]
   float lsum = 0.0f, gsum = 0.0f;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void k_crm_rows(const CrmArgs a) {
     } else {
       g = s == x ? -1.0f : 0.0f;
     }
-    float v = a.scale * (g - p * gsum);
+    float v = a.ll_in ? a.scale * g : a.scale * (g - p * gsum);
     if (x0 >= 0) v += a.nll_scale * (p - (s == x0 ? 1.0f : 0.0f));
     gr[s] = v;
   }
@@ -136,7 +141,21 @@ extern "C" int ctdd_crm_loss(const float* logits, const int32_t* xt, const int32
   CTDD_REQUIRE(B > 0 && D > 0 && S >= 2, CTDD_EINVAL, "crm loss: B=%d D=%d S=%d", B, D, S);
   CTDD_REQUIRE(loss_type >= 0 && loss_type <= 2, CTDD_EINVAL, "crm loss: loss_type %d (0 rm, 1 mle, 2 elbo)", loss_type);
   CTDD_REQUIRE(loss_type != 2 || qt0, CTDD_EINVAL, "crm loss: elbo needs q_{t|0}");
-  CrmArgs a = {logits, xt, x0, qt0, (int64_t)B * D, D, S, loss_type, scale, nll_scale, grad_logits, row_scratch};
+  CrmArgs a = {logits, xt, x0, qt0, (int64_t)B * D, D, S, loss_type, scale, nll_scale, grad_logits, row_scratch, 0};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_crm_rows, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, st, a);
+  if (int rc = finish_launch("k_crm_rows")) return rc;
+  hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, st, (const double*)row_scratch, a.rows, out_loss);
+  return finish_launch("k_sum_rows");
+}
+
+// the same objective on ll_all (reverse_prob / reverse_logscale logit types): value and d loss / d ll_all
+extern "C" int ctdd_crm_loss_ll(const float* ll_all, const int32_t* xt, const float* qt0, int B, int D, int S, int loss_type, float scale,
+                                float* grad_ll, double* row_scratch, float* out_loss, void* stream) {
+  CTDD_REQUIRE(ll_all && xt && grad_ll && row_scratch && out_loss, CTDD_EINVAL, "crm loss (ll): null buffer");
+  CTDD_REQUIRE(B > 0 && D > 0 && S >= 2, CTDD_EINVAL, "crm loss (ll): B=%d D=%d S=%d", B, D, S);
+  CTDD_REQUIRE(loss_type >= 0 && loss_type <= 2 && (loss_type != 2 || qt0), CTDD_EINVAL, "crm loss (ll): loss_type %d / elbo needs q_{t|0}", loss_type);
+  CrmArgs a = {ll_all, xt, nullptr, qt0, (int64_t)B * D, D, S, loss_type, scale, 0.0f, grad_ll, row_scratch, 1};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_crm_rows, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, st, a);
   if (int rc = finish_launch("k_crm_rows")) return rc;
@@ -173,6 +192,7 @@ struct ElboArgs {
   float* cb;          // (B)
   float* grad;        // (B,D,S)
   float* out_loss;    // (1)
+  int ll_in;          // ScoreElbo only: `logits` holds ll_all (reverse logit types); grad = d loss / d ll_all
 };
 
 // block reduction of LRB values per thread; result broadcast through red[]
@@ -421,7 +441,7 @@ extern "C" int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const in
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
   a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
   a.cb = (float*)sp;
-  a.grad = grad_logits; a.out_loss = out_loss;
+  a.grad = grad_logits; a.out_loss = out_loss; a.ll_in = 0;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_elbo_atab, dim3((S + LRB - 1) / LRB, B), dim3(256), 0, st, a);
   if (int rc = finish_launch("k_elbo_atab")) return rc;
@@ -453,12 +473,15 @@ __global__ __launch_bounds__(256) void k_selbo_fwd(const ElboArgs a, const int32
   const float* q = a.q + (size_t)b * S * S;
   const float* R = a.R + (size_t)b * S * S;
   const int x = min(max(a.xt[row], 0), S - 1), x0 = min(max(a.x0[row], 0), S - 1), xr = min(max(regx[row], 0), S - 1);
-  float m = -INFINITY;
-  for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
-  m = lwave_max(m);
-  float z = 0.0f;
-  for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
-  const float L = m + logf(lwave_sum(z));
+  float L = 0.0f;
+  if (!a.ll_in) {
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
+    m = lwave_max(m);
+    float z = 0.0f;
+    for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
+    L = m + logf(lwave_sum(z));
+  }
   const float llx = l[x] - L;
   const float qx0xt = q[(size_t)x0 * S + x] + a.eps, bsum = a.base_sum[b], rsx = -R[(size_t)x * S + x];
   float reg = 0.0f, outer = 0.0f, norm = 0.0f;
@@ -490,12 +513,15 @@ __global__ __launch_bounds__(256) void k_selbo_bwd(const ElboArgs a, const int32
   float* gr = a.grad + (size_t)row * S;
   const int x = min(max(a.xt[row], 0), S - 1), x0 = min(max(a.x0[row], 0), S - 1), xr = min(max(regx[row], 0), S - 1);
   const float cb = a.cb[b], invB = a.elbo_scale / (float)a.B;
-  float m = -INFINITY;
-  for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
-  m = lwave_max(m);
-  float z = 0.0f;
-  for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
-  const float L = m + logf(lwave_sum(z));
+  float L = 0.0f;
+  if (!a.ll_in) {
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += 64) m = fmaxf(m, l[s]);
+    m = lwave_max(m);
+    float z = 0.0f;
+    for (int s = lane; s < S; s += 64) z += expf(l[s] - m);
+    L = m + logf(lwave_sum(z));
+  }
   const float llx = l[x] - L;
   const float qx0xt = q[(size_t)x0 * S + x] + a.eps;
   auto gd = [&](int s) {                              // d loss / d dd[s], s != x
@@ -512,15 +538,29 @@ __global__ __launch_bounds__(256) void k_selbo_bwd(const ElboArgs a, const int32
   const float gsum = gs + gx;
   for (int s = lane; s < S; s += 64) {
     const float p = expf(l[s] - L);
-    gr[s] = (s == x ? gx : gd(s)) - p * gsum;
+    gr[s] = (s == x ? gx : gd(s)) - (a.ll_in ? 0.0f : p * gsum);
   }
 }
 
 }  // namespace ctdd
 
+static int score_elbo_impl(const float* logits, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x, const float* qt0,
+                           const float* rate, int B, int D, int S, float eps, float nll_scale, void* scratch, float* grad_logits,
+                           float* out_loss, int ll_in, void* stream);
 extern "C" int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x,
                                     const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
                                     void* scratch, float* grad_logits, float* out_loss, void* stream) {
+  return score_elbo_impl(logits, x0, x_tilde, reg_x, qt0, rate, B, D, S, eps, nll_scale, scratch, grad_logits, out_loss, 0, stream);
+}
+// the same objective on ll_all (reverse logit types): value and d loss / d ll_all
+extern "C" int ctdd_score_elbo_loss_ll(const float* ll_all, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x,
+                                       const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
+                                       void* scratch, float* grad_ll, float* out_loss, void* stream) {
+  return score_elbo_impl(ll_all, x0, x_tilde, reg_x, qt0, rate, B, D, S, eps, nll_scale, scratch, grad_ll, out_loss, 1, stream);
+}
+static int score_elbo_impl(const float* logits, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x, const float* qt0,
+                           const float* rate, int B, int D, int S, float eps, float nll_scale, void* scratch, float* grad_logits,
+                           float* out_loss, int ll_in, void* stream) {
   CTDD_REQUIRE(logits && x0 && x_tilde && reg_x && qt0 && rate && scratch && grad_logits && out_loss, CTDD_EINVAL, "score-elbo: null buffer");
   CTDD_REQUIRE(B > 0 && D > 0 && S >= 2 && S <= 256, CTDD_ERANGE, "score-elbo: B=%d D=%d S=%d (S <= 256)", B, D, S);
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
@@ -533,7 +573,7 @@ extern "C" int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, cons
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
   a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
   a.cb = (float*)sp;
-  a.grad = grad_logits; a.out_loss = out_loss;
+  a.grad = grad_logits; a.out_loss = out_loss; a.ll_in = ll_in;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * D;
   hipLaunchKernelGGL(k_elbo_atab, dim3(1, B), dim3(256), 0, st, a);          // (first column block only: base_sum; its A rows are unused scratch)
@@ -544,4 +584,117 @@ extern "C" int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, cons
   if (int rc = finish_launch("k_elbo_reduce")) return rc;
   hipLaunchKernelGGL(k_selbo_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, reg_x);
   return finish_launch("k_selbo_bwd");
+}
+
+// ================================================================== backward of get_logprob_with_logits for the reverse logit types
+// (reference lib/models/model_utils.py:42-56 under autograd): with p = softmax(l) and the sample's q = q_{t|0},
+//   reverse_prob      ll[s] = log(acc[s] + 1e-35),  acc = p @ q
+//   reverse_logscale  ll[s] = logsumexp_s0(log p[s0] + log q[s0][s], q <= 1e-35 -> -1e9) = log(p @ q'), q' = q [q > 1e-35]
+// Given g = d loss / d ll:  ga[s] = g[s] / (acc[s] + 1e-35)   (logscale: g / acc' where acc' > 0, else 0)
+//   dp[s0] = sum_s ga[s] q[s0][s]  (= ga @ q^T: the transposed table qT is streamed so that both contractions read rows),
+//   dl[j]  = p[j] (dp[j] - sum_s0 p[s0] dp[s0])  [+ nll_scale (p[j] - [j = x0]): the cross-entropy term of CatRMNLL, which is
+//   on the raw logits, losses.py:1240-1242; its value -log p[x0] goes to ce_rows].
+// Workgroup = 8 rows (dimensions) of one sample, thread s <-> state (S <= 256): each streamed table element feeds 8 FMAs.
+namespace ctdd {
+
+struct LpbArgs {
+  const float* logits; const float* q; const float* qT; const float* dll; const int32_t* x0;
+  int B, D, S, logit_type; float nll_scale;
+  float* grad; double* ce_rows;
+};
+__global__ __launch_bounds__(256) void k_logprob_bwd(const LpbArgs a) {
+  __shared__ __attribute__((aligned(16))) float pv[256 * LRB];      // [s0][r] p, then [s][r] ga
+  __shared__ float red[4 * LRB];
+  const int S = a.S, b = blockIdx.y, d0 = blockIdx.x * LRB, s = threadIdx.x;
+  const bool on = s < S;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* qT = a.qT + (size_t)b * S * S;
+  const bool logscale = a.logit_type == 2;
+  float l[LRB], p[LRB], m[LRB], z[LRB];
+  size_t rowoff[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const int d = min(d0 + r, a.D - 1);
+    rowoff[r] = ((size_t)b * a.D + d) * S;
+    l[r] = on ? a.logits[rowoff[r] + s] : -INFINITY;
+  }
+  block_max8(l, red, m);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) p[r] = on ? expf(l[r] - m[r]) : 0.0f;
+  block_sum8(p, red, z);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) { p[r] = p[r] / z[r]; pv[s * LRB + r] = p[r]; }
+  __syncthreads();
+  // acc[r] = sum_s0 p_r[s0] q[s0][s]
+  float acc[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) acc[r] = 0.0f;
+  if (on) {
+    for (int s0 = 0; s0 < S; ++s0) {
+      float qv = q[(size_t)s0 * S + s];
+      if (logscale && qv <= 1e-35f) qv = 0.0f;
+      const float4 p0 = *(const float4*)(pv + s0 * LRB), p1 = *(const float4*)(pv + s0 * LRB + 4);
+      acc[0] = fmaf(p0.x, qv, acc[0]); acc[1] = fmaf(p0.y, qv, acc[1]); acc[2] = fmaf(p0.z, qv, acc[2]); acc[3] = fmaf(p0.w, qv, acc[3]);
+      acc[4] = fmaf(p1.x, qv, acc[4]); acc[5] = fmaf(p1.y, qv, acc[5]); acc[6] = fmaf(p1.z, qv, acc[6]); acc[7] = fmaf(p1.w, qv, acc[7]);
+    }
+  }
+  __syncthreads();                                                    // pv is read: reuse it for ga
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    float ga = 0.0f;
+    if (on && d0 + r < a.D) {
+      const float g = a.dll[rowoff[r] + s];
+      ga = logscale ? (acc[r] > 0.0f ? g / acc[r] : 0.0f) : g / (acc[r] + 1e-35f);
+    }
+    pv[s * LRB + r] = ga;
+  }
+  __syncthreads();
+  // dp[r] (this thread: s0 = s) = sum_s' ga_r[s'] qT[s'][s0]
+  float dp[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) dp[r] = 0.0f;
+  if (on) {
+    for (int sp = 0; sp < S; ++sp) {
+      float qv = qT[(size_t)sp * S + s];
+      if (logscale && qv <= 1e-35f) qv = 0.0f;
+      const float4 g0 = *(const float4*)(pv + sp * LRB), g1 = *(const float4*)(pv + sp * LRB + 4);
+      dp[0] = fmaf(g0.x, qv, dp[0]); dp[1] = fmaf(g0.y, qv, dp[1]); dp[2] = fmaf(g0.z, qv, dp[2]); dp[3] = fmaf(g0.w, qv, dp[3]);
+      dp[4] = fmaf(g1.x, qv, dp[4]); dp[5] = fmaf(g1.y, qv, dp[5]); dp[6] = fmaf(g1.z, qv, dp[6]); dp[7] = fmaf(g1.w, qv, dp[7]);
+    }
+  }
+  float pd[LRB], dot[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) pd[r] = p[r] * dp[r];
+  block_sum8(pd, red, dot);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    if (!(on && d0 + r < a.D)) continue;
+    float v = p[r] * (dp[r] - dot[r]);
+    if (a.x0) {
+      const int x0 = min(max(a.x0[(size_t)b * a.D + d0 + r], 0), S - 1);
+      v += a.nll_scale * (p[r] - (s == x0 ? 1.0f : 0.0f));
+      if (s == x0 && a.ce_rows) a.ce_rows[(size_t)b * a.D + d0 + r] = (double)a.nll_scale * (double)(-(l[r] - m[r] - logf(z[r])));
+    }
+    a.grad[rowoff[r] + s] = v;
+  }
+}
+
+}  // namespace ctdd
+
+extern "C" int ctdd_logprob_bwd(int logit_type, const float* logits, const float* qt0, const float* qt0T, const float* dll,
+                                const int32_t* x0, float nll_scale, int B, int D, int S, float* grad_logits, double* ce_rows,
+                                float* out_ce, void* stream) {
+  CTDD_REQUIRE(logits && qt0 && qt0T && dll && grad_logits, CTDD_EINVAL, "logprob bwd: null buffer");
+  CTDD_REQUIRE(logit_type == 1 || logit_type == 2, CTDD_EINVAL, "logprob bwd: logit_type %d (1 reverse_prob, 2 reverse_logscale)", logit_type);
+  CTDD_REQUIRE(B > 0 && D > 0 && S >= 2 && S <= 256, CTDD_ERANGE, "logprob bwd: B=%d D=%d S=%d (S <= 256)", B, D, S);
+  CTDD_REQUIRE(!x0 || (ce_rows && out_ce), CTDD_EINVAL, "logprob bwd: the cross-entropy term needs ce_rows and out_ce");
+  LpbArgs a = {logits, qt0, qt0T, dll, x0, B, D, S, logit_type, nll_scale, grad_logits, ce_rows};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_logprob_bwd, dim3((D + LRB - 1) / LRB, B), dim3(256), 0, st, a);
+  if (int rc = finish_launch("k_logprob_bwd")) return rc;
+  if (x0) {
+    hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, st, (const double*)ce_rows, (int64_t)B * D, out_ce);
+    return finish_launch("k_sum_rows");
+  }
+  return CTDD_OK;
 }

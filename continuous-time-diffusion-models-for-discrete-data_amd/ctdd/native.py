@@ -54,6 +54,9 @@ _SIGS = {
     "ctdd_ctelbo_scratch_bytes": ([_I, _I, _I], _I64),
     "ctdd_ctelbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_score_elbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
+    "ctdd_crm_loss_ll": ([_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),
+    "ctdd_score_elbo_loss_ll": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
+    "ctdd_logprob_bwd": ([_I, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_opt_chunk_elems": ([], _I),
     "ctdd_adam_ema_step": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
     "ctdd_grad_sumsq": ([_P, _P, _I, _P, _I, _P], _I),
@@ -280,6 +283,57 @@ def crm_loss(logits, xt, x0, qt0, loss_type, scale, nll_scale):
                                 _ptr(qt0, torch.float32, "qt0") if qt0 is not None else None, B, D, S, lt, float(scale),
                                 float(nll_scale), _ptr(grad), _ptr(rows), _ptr(out), _stream()), "ctdd_crm_loss")
     return out[0], grad
+
+
+LAUNCH_COUNTS = {}      # entry point -> calls (tests assert that an objective really ran through the HIP path)
+
+
+def _count(name):
+    LAUNCH_COUNTS[name] = LAUNCH_COUNTS.get(name, 0) + 1
+
+
+def crm_loss_ll(ll_all, xt, qt0, loss_type, scale):
+    """K12 on ll_all (reverse logit types): (loss scalar tensor, d loss / d ll_all)."""
+    B, D, S = ll_all.shape
+    grad = torch.empty_like(ll_all)
+    rows = torch.empty((B * D,), dtype=torch.float64, device=ll_all.device)
+    out = torch.empty((1,), dtype=torch.float32, device=ll_all.device)
+    lt = {"rm": 0, "mle": 1, "elbo": 2}[loss_type]
+    _check(load().ctdd_crm_loss_ll(_ptr(ll_all, torch.float32, "ll_all"), _ptr(xt, torch.int32, "xt"),
+                                   _ptr(qt0, torch.float32, "qt0") if qt0 is not None else None, B, D, S, lt, float(scale),
+                                   _ptr(grad), _ptr(rows), _ptr(out), _stream()), "ctdd_crm_loss_ll")
+    _count("ctdd_crm_loss_ll")
+    return out[0], grad
+
+
+def score_elbo_loss_ll(ll_all, x0, x_tilde, reg_x, qt0, rate, eps, nll_scale):
+    """ScoreElbo on ll_all (reverse logit types): (loss scalar tensor, d loss / d ll_all)."""
+    B, D, S = ll_all.shape
+    lib = load()
+    scratch = torch.empty((int(lib.ctdd_ctelbo_scratch_bytes(B, D, S)),), dtype=torch.uint8, device=ll_all.device)
+    grad = torch.empty_like(ll_all)
+    out = torch.empty((1,), dtype=torch.float32, device=ll_all.device)
+    _check(lib.ctdd_score_elbo_loss_ll(_ptr(ll_all, torch.float32, "ll_all"), _ptr(x0, torch.int32, "x0"), _ptr(x_tilde, torch.int32, "x_tilde"),
+                                       _ptr(reg_x, torch.int32, "reg_x"), _ptr(qt0, torch.float32, "qt0"), _ptr(rate, torch.float32, "rate"),
+                                       B, D, S, float(eps), float(nll_scale), _ptr(scratch), _ptr(grad), _ptr(out), _stream()),
+           "ctdd_score_elbo_loss_ll")
+    _count("ctdd_score_elbo_loss_ll")
+    return out[0], grad
+
+
+def logprob_bwd(logit_type, logits, qt0, qt0T, dll, x0=None, nll_scale=0.0):
+    """d/dlogits of ll_all = get_logprob_with_logits(logits) for the reverse logit types given dll = d loss / d ll_all;
+    x0: also the cross-entropy term nll_scale * sum -log_softmax(logits)[x0] (gradient added, value returned)."""
+    B, D, S = logits.shape
+    grad = torch.empty_like(logits)
+    ce_rows = torch.zeros((B * D,), dtype=torch.float64, device=logits.device) if x0 is not None else None
+    out_ce = torch.zeros((1,), dtype=torch.float32, device=logits.device)
+    _check(load().ctdd_logprob_bwd(LOGIT_TYPES[logit_type], _ptr(logits, torch.float32, "logits"), _ptr(qt0, torch.float32, "qt0"),
+                                   _ptr(qt0T, torch.float32, "qt0T"), _ptr(dll, torch.float32, "dll"),
+                                   _ptr(x0, torch.int32, "x0") if x0 is not None else None, float(nll_scale), B, D, S, _ptr(grad),
+                                   _ptr(ce_rows) if ce_rows is not None else None, _ptr(out_ce), _stream()), "ctdd_logprob_bwd")
+    _count("ctdd_logprob_bwd")
+    return grad, out_ce[0]
 
 
 def score_elbo_loss(logits, x0, x_tilde, reg_x, qt0, rate, eps, nll_scale):

@@ -224,6 +224,57 @@ class _CrmLossFn(torch.autograd.Function):
         return grad * g, None, None, None, None, None, None
 
 
+def _tables_with_transpose(model, ts):
+    """(q_{t|0}, its transpose), each (B,S,S): the transpose straight out of K1 when the model carries a device process."""
+    pr = getattr(model, "process", None)
+    if pr is not None and hasattr(pr, "tables"):
+        qt0, qT, _, _ = pr.tables(ts, want_qt0=True, want_qt0T=True)
+        return qt0, qT
+    qt0 = model.transition(ts).float().contiguous()
+    return qt0, qt0.transpose(1, 2).contiguous()
+
+
+class _CrmRevFn(torch.autograd.Function):
+    """CRM objectives for logit_type reverse_prob / reverse_logscale in HIP: ctdd_logprob -> K12 on ll_all -> ctdd_logprob_bwd
+    (+ CatRMNLL's cross-entropy term on the raw logits inside the last launch)."""
+
+    @staticmethod
+    def forward(ctx, logits, xt, x0, qt0, qt0T, logit_type, loss_type, scale, nll_scale):
+        lg = logits.detach().float().contiguous()
+        xti = xt.to(torch.int32).contiguous()
+        tidx = torch.arange(lg.shape[0], dtype=torch.int32, device=lg.device)
+        ll_all, _ = native.logprob(lg, xti, qt0, logit_type, tidx)
+        val, dll = native.crm_loss_ll(ll_all, xti, qt0 if loss_type == "elbo" else None, loss_type, scale)
+        grad, ce = native.logprob_bwd(logit_type, lg, qt0, qt0T, dll, None if x0 is None else x0.to(torch.int32).contiguous(), nll_scale)
+        ctx.save_for_backward(grad)
+        return val if x0 is None else val + ce
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g,) + (None,) * 8
+
+
+class _ScoreElboRevFn(torch.autograd.Function):
+    """ScoreElbo for the reverse logit types in HIP (same three-launch chain)."""
+
+    @staticmethod
+    def forward(ctx, logits, x0, x_tilde, reg_x, qt0, qt0T, rate, logit_type, eps, nll_scale):
+        lg = logits.detach().float().contiguous()
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        tidx = torch.arange(lg.shape[0], dtype=torch.int32, device=lg.device)
+        ll_all, _ = native.logprob(lg, i32(x_tilde), qt0, logit_type, tidx)
+        val, dll = native.score_elbo_loss_ll(ll_all, i32(x0), i32(x_tilde), i32(reg_x), qt0, rate.contiguous(), eps, nll_scale)
+        grad, _ = native.logprob_bwd(logit_type, lg, qt0, qt0T, dll)
+        ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g,) + (None,) * 9
+
+
 def _crm_objective(cfg, model, logits, xt, ts, x0, nll_weight):
     """sum(loss_bd) (1 - ce_coeff) / B [+ nll_weight * CE(logits, x0)]; direct logits on a GPU run in K12."""
     B, D = xt.shape
@@ -232,7 +283,11 @@ def _crm_objective(cfg, model, logits, xt, ts, x0, nll_weight):
         qt0 = model.transition(ts) if cfg.loss.loss_type == "elbo" else None
         return _CrmLossFn.apply(logits, xt, x0 if nll_weight else None, qt0, cfg.loss.loss_type, scale,
                                 float(nll_weight) / (B * D) if nll_weight else 0.0)
-    ll_all, ll_xt = get_logprob_with_logits(cfg, model, xt, ts, logits)      # reverse_prob / reverse_logscale: device ops
+    if logits.is_cuda and cfg.loss.logit_type in ("reverse_prob", "reverse_logscale") and logits.shape[-1] <= 256 and getattr(cfg.loss, "fused", True):
+        qt0, qT = _tables_with_transpose(model, ts)
+        return _CrmRevFn.apply(logits, xt, x0 if nll_weight else None, qt0, qT, cfg.loss.logit_type, cfg.loss.loss_type, scale,
+                               float(nll_weight) / (B * D) if nll_weight else 0.0)
+    ll_all, ll_xt = get_logprob_with_logits(cfg, model, xt, ts, logits)      # (cfg.device == "cpu", S > 256, cfg.loss.fused = False)
     out = torch.sum(_crm_loss(cfg, model, xt, ts, ll_all, ll_xt)) * scale
     if nll_weight:
         out = out + nll_weight * F.cross_entropy(logits.permute(0, 2, 1), x0)
@@ -328,6 +383,11 @@ class ScoreElbo:
         logits = model(reg_x, ts)
         if self.cfg.loss.logit_type == "direct" and logits.is_cuda and logits.shape[-1] <= 256 and getattr(self.cfg.loss, "fused", True):
             return _ScoreElboFn.apply(logits, x0, x_tilde, reg_x, qt0, rate, float(eps), float(self.nll_weight) / B)
+        if (self.cfg.loss.logit_type in ("reverse_prob", "reverse_logscale") and logits.is_cuda and logits.shape[-1] <= 256
+                and getattr(self.cfg.loss, "fused", True)):
+            _, qT = _tables_with_transpose(model, ts)
+            return _ScoreElboRevFn.apply(logits, x0, x_tilde, reg_x, qt0.contiguous(), qT, rate, self.cfg.loss.logit_type, float(eps),
+                                         float(self.nll_weight) / B)
         n = torch.arange(B, device=x0.device).view(B, 1)
         rT = rate.transpose(1, 2)
         ll_all, ll_xt = get_logprob_with_logits(self.cfg, model, x_tilde, ts, logits)

@@ -207,6 +207,22 @@ int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, const int32_t* 
                          const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
                          void* scratch, float* grad_logits, float* out_loss, void* stream);
 
+/* ---- the same objectives for logit_type 'reverse_prob' / 'reverse_logscale' (model_utils.py:42-56; every shipped hollow
+ * config uses reverse_prob): three launches chained on the device --
+ *   ctdd_logprob (above)            logits -> ll_all = log p_t(. | x^{\d})
+ *   ctdd_crm_loss_ll / ctdd_score_elbo_loss_ll   the objective on ll_all: value and grad_ll = d out_loss / d ll_all
+ *   ctdd_logprob_bwd                grad_ll -> d/dlogits through ll = log(softmax(logits) @ q_{t|0} (+1e-35)); x0 non-null adds
+ *                                   CatRMNLL's cross-entropy term nll_scale * sum -log_softmax(logits)[x0] (losses.py:1240-1242):
+ *                                   its gradient to grad_logits, its value to out_ce (ce_rows: B*D doubles).  S <= 256. */
+int ctdd_crm_loss_ll(const float* ll_all, const int32_t* xt, const float* qt0, int B, int D, int S, int loss_type, float scale,
+                     float* grad_ll, double* row_scratch, float* out_loss, void* stream);
+int ctdd_score_elbo_loss_ll(const float* ll_all, const int32_t* x0, const int32_t* x_tilde, const int32_t* reg_x,
+                            const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
+                            void* scratch, float* grad_ll, float* out_loss, void* stream);
+int ctdd_logprob_bwd(int logit_type, const float* logits, const float* qt0, const float* qt0T, const float* dll,
+                     const int32_t* x0, float nll_scale, int B, int D, int S, float* grad_logits, double* ce_rows,
+                     float* out_ce, void* stream);
+
 /* ---- K28: clip_grad_norm_ + Adam.step + EMA update over all parameter tensors in two launches
  * (lib/training/training.py:17-40, lib/models/models.py:745-758, torch.optim.Adam single-tensor formulas).
  * tensors: device array of ctdd_opt_tensor; chunks: device array of ctdd_opt_chunk covering every tensor in

@@ -57,6 +57,8 @@ def test_objective_matches_oracle_on_identical_noise(golden, tag):
     model = DeviceThetaToy(m["kind"], m["S"], m["t_func"], m["theta"])
     loss = lu.get_loss(_cfg(m))
     L._FIXED_NOISE = {"ts": ts, "x_t": x_t, "x_tilde": x_tilde if x_tilde is not None else x_t}
+    from ctdd import native
+    before = dict(native.LAUNCH_COUNTS)
     try:
         state = {"model": model, "n_iter": m["n_iter"]}
         x0 = T(g[f"{tag}__x0"]).cuda()
@@ -64,6 +66,10 @@ def test_objective_matches_oracle_on_identical_noise(golden, tag):
         grad, = torch.autograd.grad(val, model.theta)
     finally:
         L._FIXED_NOISE = None
+    if m["loss"] in ("CatRM", "CatRMNLL", "ScoreElbo") and m["logit_type"] != "direct":
+        # the reverse logit types (what every shipped hollow config uses) run the HIP chain, not torch device ops
+        ran = {k: native.LAUNCH_COUNTS.get(k, 0) - before.get(k, 0) for k in ("ctdd_logprob_bwd", "ctdd_crm_loss_ll", "ctdd_score_elbo_loss_ll")}
+        assert ran["ctdd_logprob_bwd"] == 1 and ran["ctdd_crm_loss_ll"] + ran["ctdd_score_elbo_loss_ll"] == 1, ran
     # same tables on both sides would make this ~1e-6; the GPU builds q_{t|0} itself (K1), rtol 2e-4
     np.testing.assert_allclose(val.item(), oval.item(), rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(grad.item(), ograd.item(), rtol=2e-3, atol=1e-5)
@@ -137,3 +143,33 @@ def test_crm_kernel_matches_oracle_formulas(S, D, loss_type):
                                 nllw / (B * D))
     np.testing.assert_allclose(val.item(), want.item(), rtol=2e-5)
     np.testing.assert_allclose(grad.cpu().numpy(), wgrad.numpy(), rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("S,D", [(3, 15), (256, 37), (100, 9)])
+@pytest.mark.parametrize("logit_type", ["reverse_prob", "reverse_logscale"])
+@pytest.mark.parametrize("loss_type", ["rm", "mle", "elbo"])
+def test_crm_reverse_logit_types_match_oracle_formulas(S, D, logit_type, loss_type):
+    """ctdd_logprob -> ctdd_crm_loss_ll -> ctdd_logprob_bwd against autograd through the oracle's restatement of
+    get_logprob_with_logits (model_utils.py:42-56) + the CRM objective + CE on random logits: value and d/dlogits."""
+    from ctdd import native
+    from oracle import losses as ol, ctmc_ops as ops
+    import lib.losses.losses as L
+    import torch.nn.functional as F
+    B = 3
+    g = torch.Generator().manual_seed(S * 7 + D)
+    logits = torch.randn(B, D, S, generator=g) * 2.0
+    xt = torch.randint(0, S, (B, D), generator=g)
+    x0 = torch.randint(0, S, (B, D), generator=g)
+    qt0 = torch.softmax(torch.randn(B, S, S, generator=g) * 2, -1)
+    qt0[qt0 < 1e-4] = 0.0                                        # exact zeros as the clamped transition tables have
+    scale, nllw = 0.7 / B, 0.05
+    lo = logits.clone().requires_grad_(True)
+    ll_all, ll_xt = ops.logprob_with_logits(logit_type, lo, xt, qt0)
+    want = torch.sum(ol.crm_comp_loss(loss_type, S, ll_all, ll_xt, xt, qt0)) * scale + nllw * F.cross_entropy(lo.permute(0, 2, 1), x0)
+    wgrad, = torch.autograd.grad(want, lo)
+    lg = logits.cuda().requires_grad_(True)
+    q = qt0.cuda()
+    val = L._CrmRevFn.apply(lg, xt.cuda(), x0.cuda(), q, q.transpose(1, 2).contiguous(), logit_type, loss_type, scale, nllw / (B * D))
+    grad, = torch.autograd.grad(val, lg)
+    np.testing.assert_allclose(val.item(), want.item(), rtol=3e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), wgrad.numpy(), rtol=5e-4, atol=1e-6 * wgrad.abs().max().item() + 1e-9)
