@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode timing")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing")
     ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
     ap.add_argument("--model-opt", action="append", default=[], help="integer engine option, key=value (tuning sweeps)")
     return ap.parse_args()
@@ -178,6 +179,42 @@ def fp32_parity_mode(cfg, model, sampler, batch, steps=6, warmup=2):
             "dtype": "f32", "note": "score network on v_mfma_f32_32x32x2_f32 (logits within 1e-4 of the reference's goldens); same fused tau-leap launch"}
 
 
+def train_step_timing(batch=64, steps=10, warmup=4):
+    """One MNIST tauLDR CT-ELBO training step (config_tauUnet_mnist, batch 64: zero_grad -> noising + CT-ELBO (K2/K3/K11) ->
+    backward -> clip + Adam + EMA (K28)) with the score network on the hand-written training plan (ctdd/unet_train.py) and,
+    next to it, on torch autograd device ops (what round 1 trained with)."""
+    import lib.losses.losses  # noqa: F401
+    import lib.losses.losses_utils as lu
+    import lib.models.model_utils as mu
+    import lib.optimizers.optimizers  # noqa: F401
+    import lib.optimizers.optimizers_utils as ou
+    import lib.training.training  # noqa: F401
+    import lib.training.training_utils as tu
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    out = {}
+    for tag, engine in (("hip_plan_bf16", "hip"), ("torch_autograd_fp32", "torch")):
+        cfg = get_config()
+        cfg.model.engine = engine
+        torch.manual_seed(0)
+        model = mu.create_model(cfg, torch.device("cuda"))
+        state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+        step, loss = tu.get_train_step(cfg), lu.get_loss(cfg)
+        mb = torch.randint(0, S, (batch, 1, 28, 28), device="cuda")
+        for _ in range(warmup):
+            step.step(state, loss, mb)
+            state["n_iter"] += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step.step(state, loss, mb)
+            state["n_iter"] += 1
+        torch.cuda.synchronize()
+        out[tag] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        del model, state
+    return {"workload": f"MNIST tauLDR CT-ELBO training step, batch {batch} (Standard.step: loss + backward + clip + Adam + EMA)",
+            "ms_per_step": out, "speedup": round(out["torch_autograd_fp32"] / out["hip_plan_bf16"], 2)}
+
+
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
     """The CPU oracle (restatement of the reference's CPU path, pinned by tests/golden) doing the
     same tau-leaping step on the host cores: oracle U-Net forward + reverse rates + torch.poisson
@@ -291,6 +328,8 @@ def main():
             "roofline_mid_trajectory": None if roof_mid is None else {k_: roof_mid[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "mfma_view")},
             "fp32_parity_mode": fp32_mode,
         }
+        if world == 1 and not a.no_train_step:
+            line["train_step"] = train_step_timing()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, cfg, a.cpu_batch)
         print(json.dumps(line), flush=True)
