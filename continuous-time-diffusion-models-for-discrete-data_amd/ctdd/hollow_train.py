@@ -1,0 +1,503 @@
+"""Training path of the SDDM hollow transformer on hand-written HIP kernels (reference: forward + `l.backward()` through
+TAUnSDDM/lib/networks/hollow_networks.py:668-755 and the blocks it is built from).
+
+`HollowTrainer(model)(x, t)` computes the logits of a `BidirectionalTransformer2` with every operation a libctdd launch and
+autograd as the tape only: each operation is a `torch.autograd.Function` whose forward and backward call the C ABI
+(include/ctdd_hollow.h, ctdd_hollow_train.h, ctdd_unet.h, ctdd_unet_train.h):
+
+  linear layers      forward / data gradient: the implicit-GEMM kernels (`ctdd_unet_conv_patch` bf16 operands, `ctdd_unet_conv`
+                     exact fp32) -- the data gradient is the same GEMM with the transposed weight; weight gradient
+                     `ctdd_unet_wgrad` (kind 1x1: tokens are the contraction index), bias gradient `ctdd_unet_colsum`
+  LayerNorm (+FiLM)  `ctdd_hollow_layernorm` / `ctdd_hollow_layernorm_bwd`
+  attention          `ctdd_hollow_attention_train` (dropout on the probabilities inside the kernel) / `ctdd_hollow_attention_bwd`
+  ReLU / GELU, dropout, embedding, l2r + r2l   `ctdd_hollow_act`, `ctdd_unet_dropout`, `ctdd_hollow_embed(_bwd)`, `ctdd_hollow_add`
+
+Parameters enter the Functions directly, so their gradients are ordinary autograd gradients (DistributedDataParallel hooks
+work unchanged).  Dropout masks are Philox(seed, step, layer, element): the backward of a step regenerates the forward's.
+precision "fp32": exact-fp32 matrix instructions everywhere (parity mode); "bf16": bf16 GEMM operands, fp32 accumulation,
+fp32 attention / LayerNorm / residual streams.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import native
+from .unet_engine import SEG_1x1, _ConvArgs, _unwrap
+from .hollow_engine import _AttnArgs as _InfAttnArgs, _EmbedArgs, _LnArgs, _lib as _hollow_lib, supports  # noqa: F401
+from . import unet_train
+
+_P, _I, _F, _I64, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
+
+
+class _LnBwdArgs(C.Structure):
+    _fields_ = [("x", _P), ("y", _P), ("x_bs", _I64), ("y_bs", _I64), ("gamma", _P), ("beta", _P), ("eps", _F), ("film", _P),
+                ("film_stride", _I), ("dout", _P), ("dout_bs", _I64), ("B", _I), ("T", _I), ("E", _I), ("rpw", _I), ("dx", _P),
+                ("dx_bs", _I64), ("acc_dx", _I), ("dy", _P), ("dy_bs", _I64), ("acc_dy", _I), ("dgamma", _P), ("dbeta", _P), ("dfilm", _P)]
+
+
+class _AttnTrainArgs(C.Structure):
+    _fields_ = [("q", _P), ("k", _P), ("v", _P), ("q_bs", _I64), ("k_bs", _I64), ("v_bs", _I64), ("q_rs", _I), ("k_rs", _I), ("v_rs", _I),
+                ("B", _I), ("Tq", _I), ("Tk", _I), ("H", _I), ("hd", _I), ("mode", _I), ("scale", _F), ("out", _P), ("out_rs", _I),
+                ("stats", _P), ("drop_p", _F), ("rng", _P), ("layer", _U64), ("d_out", _P), ("dq", _P), ("dk", _P), ("dv", _P),
+                ("dq_bs", _I64), ("dk_bs", _I64), ("dv_bs", _I64), ("dq_rs", _I), ("dk_rs", _I), ("dv_rs", _I)]
+
+
+class _EmbedBwdArgs(C.Structure):
+    _fields_ = [("x64", _P), ("x32", _P), ("dl2r", _P), ("dr2l", _P), ("B", _I), ("D", _I), ("E", _I), ("S", _I), ("dw", _P), ("db", _P)]
+
+
+_sigs_done = False
+
+
+def lib():
+    global _sigs_done
+    l = _hollow_lib()
+    unet_train.lib()
+    if not _sigs_done:
+        for name, argt in (("ctdd_hollow_layernorm_bwd", [_P, _P]), ("ctdd_hollow_attention_train", [_P, _P]),
+                           ("ctdd_hollow_attention_bwd", [_P, _P]),
+                           ("ctdd_hollow_act", [_P, _P, _P, _P, _I64, _I, _F, _P, _U64, _P]), ("ctdd_hollow_embed_bwd", [_P, _P])):
+            fn = getattr(l, name)
+            fn.argtypes, fn.restype = argt, _I
+        _sigs_done = True
+    return l
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise native.CtddError(f"{what} failed ({rc}): {native.load().ctdd_last_error().decode()}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------- GEMM on the implicit-GEMM kernels
+def _gemm(x, w, bias, res, rows, K, N, bf16):
+    """out[rows][N] (fp32) = x[rows][K] @ w[N][K]^T (+ bias) (+ res).  x, w: fp32, or bf16 when `bf16`."""
+    l = lib()
+    out = torch.empty((rows, N), dtype=torch.float32, device=x.device)
+    a = _ConvArgs()
+    a.nseg = 1
+    a.seg[0].C, a.seg[0].kind = K, SEG_1x1
+    if bf16:
+        a.seg[0].hi, a.w_hi = x.data_ptr(), w.data_ptr()
+    else:
+        a.seg[0].f32, a.w_f32 = x.data_ptr(), w.data_ptr()
+    a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = 1, rows, 1, rows, 1, N, K
+    a.bias, a.res_f32, a.out_f32 = _p(bias), _p(res), out.data_ptr()
+    if bf16 and N % 8 == 0:
+        pbk = 64 if K % 64 == 0 else 48 if K % 48 == 0 else 32 if K % 32 == 0 else 16
+        if pbk == 64:
+            pbnt = 4 if N > 64 else 2 if N > 32 else 1
+        elif pbk == 48:
+            pbnt = 4 if N % 128 == 0 else 3 if N > 64 else 2 if N > 32 else 1
+        elif pbk == 32:
+            pbnt = 4 if N % 128 == 0 else 3 if N > 32 else 1
+        else:
+            pbnt = 1
+        _ck(l.ctdd_unet_conv_patch(C.byref(a), pbk, pbnt, 32, _st()), "ctdd_unet_conv_patch")
+    elif bf16:
+        bk = 96 if K % 96 == 0 else 64 if K % 64 == 0 else 32 if K % 32 == 0 else 16
+        _ck(l.ctdd_unet_conv(C.byref(a), bk, 1, 0, _st()), "ctdd_unet_conv")
+    else:
+        bk = 32 if K % 32 == 0 else 16
+        bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
+        _ck(l.ctdd_unet_conv(C.byref(a), bk, bnt, 1, _st()), "ctdd_unet_conv")
+    return out
+
+
+def _cast(x, rows, n, ld_out, bf16):
+    """fp32 rows of n values -> rows of ld_out (zero padded) in the GEMM operand type."""
+    out = torch.empty((rows, ld_out), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device)
+    _ck(lib().ctdd_unet_cast_rows(x.data_ptr(), rows, n, n, ld_out, out.data_ptr() if bf16 else None, None if bf16 else out.data_ptr(), _st()),
+        "ctdd_unet_cast_rows")
+    return out
+
+
+_tables = {}
+
+
+def _device_table(raw, dev):
+    """Device copy of a launch table; the caching allocator hands a steady-state training step the same buffers every
+    iteration, so the tables repeat and are uploaded once."""
+    key = (raw, dev.index)
+    t = _tables.get(key)
+    if t is None:
+        if len(_tables) > 4096:
+            _tables.clear()
+        t = _tables[key] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    return t
+
+
+def _wgrad_geometry(rows, N, K, bf16, budget=144 * 1024):
+    """(nwn, nlr) of a one-tap weight-gradient entry: as unet_train.TrainCtx.wgrad_geometry (kernel LDS + staging-slot limits)."""
+    tb, epv = (64, 8) if bf16 else (128, 4)
+    for nwn in ([1, 2, 4] if N <= 32 else ([4, 2, 1] if K <= 32 else [2, 4, 1])):
+        nwc = 4 // nwn
+        nlr = min(budget // ((nwn + nwc) * tb), 2048 // (32 * nwn // epv), 2560 // (32 * nwc // epv)) // 16 * 16
+        if nlr >= 16:
+            return nwn, min(nlr, -(-rows // 16) * 16)
+    raise native.CtddError("weight gradient: no chunk fits the kernel's staging slots")
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b (+ res); x (rows, K) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, bf16):
+        rows, K = x.shape
+        N = w.shape[0]
+        x = x.contiguous()
+        xo = _cast(x, rows, K, K, True) if bf16 else x
+        wo = w.detach().to(torch.bfloat16).contiguous() if bf16 else w.detach().contiguous()
+        out = _gemm(xo, wo, None if b is None else b.detach(), None if res is None else res.contiguous(), rows, K, N, bf16)
+        ctx.save_for_backward(xo, w)
+        ctx.bf16, ctx.has_b, ctx.has_res = bf16, b is not None, res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xo, w = ctx.saved_tensors
+        bf16 = ctx.bf16
+        rows, K = xo.shape
+        N = w.shape[0]
+        l = lib()
+        dy = dy.contiguous()
+        ld = -(-N // 16) * 16
+        dyo = _cast(dy, rows, N, ld, bf16) if (bf16 or ld != N) else dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # data gradient: the same GEMM with the transposed weight [K][ld] (columns >= N zero)
+            wt = torch.zeros((K, ld), dtype=dyo.dtype, device=dy.device)
+            wt[:, :N] = w.detach().t().to(dyo.dtype)
+            dx = _gemm(dyo, wt, None, None, rows, ld, K, bf16)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+            a = unet_train._WgradArgs()
+            a.x, a.dy, a.gw = xo.data_ptr(), dyo.data_ptr(), dw.data_ptr()
+            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind = 1, rows, 1, rows, 1, N, ld, K, K, 0, unet_train.WG_1x1
+            a.nwn, a.nlr = _wgrad_geometry(rows, N, K, bf16)
+            a.nchunks = -(-rows // a.nlr)
+            groups = -(-N // (32 * a.nwn)) * -(-K // (32 * (4 // a.nwn)))
+            a.grid_x, a.tap = max(1, min(a.nchunks, -(-768 // groups))), 0
+            tab = (unet_train._WgradArgs * 1)(a)
+            _ck(l.ctdd_unet_wgrad(_device_table(bytes(tab), dy.device).data_ptr(), C.addressof(tab), 1, 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            n8 = -(-N // 8) * 8
+            tmp = torch.zeros((n8,), dtype=torch.float32, device=dy.device)
+            _ck(l.ctdd_unet_colsum(None if bf16 else dyo.data_ptr(), dyo.data_ptr() if bf16 else None, 1, rows, n8, ld, None, 0, tmp.data_ptr(),
+                                   _st()), "ctdd_unet_colsum")
+            db = tmp[:N]
+        return dx, dw, db, (dy if ctx.has_res else None), None
+
+
+def linear(x, lin_w, lin_b, bf16, res=None):
+    return LinearFn.apply(x, lin_w, lin_b, res, bf16)
+
+
+# ---------------------------------------------------------------------- LayerNorm (+ add, + FiLM)
+class LayerNormFn(torch.autograd.Function):
+    """out = FiLM_b(LayerNorm(x (+ y))): x, y (B, T, E) contiguous; film (B, 2E) or None."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, film, eps):
+        B, T, E = x.shape
+        x = x.contiguous()
+        y = None if y is None else y.contiguous()
+        out = torch.empty_like(x)
+        a = _LnArgs()
+        a.x, a.y, a.x_bs, a.y_bs, a.out_bs = x.data_ptr(), _p(y), T * E, T * E, T * E
+        a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+        a.film, a.film_stride, a.B, a.T, a.E, a.out = _p(film), 0 if film is None else film.shape[1], B, T, E, out.data_ptr()
+        _ck(lib().ctdd_hollow_layernorm(C.byref(a), _st()), "ctdd_hollow_layernorm")
+        ctx.save_for_backward(x, y, gamma, beta, film)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, gamma, beta, film = ctx.saved_tensors
+        B, T, E = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+        dfilm = None if film is None else torch.zeros_like(film)
+        a = _LnBwdArgs()
+        a.x, a.y, a.x_bs, a.y_bs = x.data_ptr(), _p(y), T * E, T * E
+        a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), ctx.eps
+        a.film, a.film_stride = _p(film), 0 if film is None else film.shape[1]
+        a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 8
+        a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, 0
+        a.dgamma, a.dbeta, a.dfilm = dg.data_ptr(), db.data_ptr(), _p(dfilm)
+        _ck(lib().ctdd_hollow_layernorm_bwd(C.byref(a), _st()), "ctdd_hollow_layernorm_bwd")
+        return dx, (dx if y is not None else None), dg, db, dfilm, None
+
+
+# ---------------------------------------------------------------------- attention
+class AttentionFn(torch.autograd.Function):
+    """Masked multi-head attention softmax(q k^T / sqrt(hd)) v with dropout on the probabilities.
+    self-attention: qkv (B*T, 3E) with k = None;  readout: q (B*Tq, E), k, v (B*Tk, E)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer):
+        E = H * hd
+        q = q.contiguous()
+        out = torch.empty((B * Tq, E), dtype=torch.float32, device=q.device)
+        stats = torch.empty((B, H, Tq, 4), dtype=torch.float32, device=q.device)
+        a = _AttnTrainArgs()
+        if k is None:                                   # packed qkv rows
+            a.q, a.k, a.v = q.data_ptr(), q.data_ptr() + 4 * E, q.data_ptr() + 8 * E
+            a.q_bs = a.k_bs = a.v_bs = Tq * 3 * E
+            a.q_rs = a.k_rs = a.v_rs = 3 * E
+        else:
+            k, v = k.contiguous(), v.contiguous()
+            a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+            a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
+        a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd)
+        a.out, a.out_rs, a.stats = out.data_ptr(), E, stats.data_ptr()
+        a.drop_p, a.rng, a.layer = float(drop_p), _p(rng), int(layer)
+        _ck(lib().ctdd_hollow_attention_train(C.byref(a), _st()), "ctdd_hollow_attention_train")
+        ctx.save_for_backward(q, k, v, out, stats, rng)
+        ctx.meta = (B, Tq, Tk, H, hd, mode, float(drop_p), int(layer))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, stats, rng = ctx.saved_tensors
+        B, Tq, Tk, H, hd, mode, drop_p, layer = ctx.meta
+        E = H * hd
+        dout = dout.contiguous()
+        a = _AttnTrainArgs()
+        if k is None:
+            dqkv = torch.empty_like(q)
+            a.q, a.k, a.v = q.data_ptr(), q.data_ptr() + 4 * E, q.data_ptr() + 8 * E
+            a.q_bs = a.k_bs = a.v_bs = Tq * 3 * E
+            a.q_rs = a.k_rs = a.v_rs = 3 * E
+            a.dq, a.dk, a.dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * E, dqkv.data_ptr() + 8 * E
+            a.dq_bs = a.dk_bs = a.dv_bs = Tq * 3 * E
+            a.dq_rs = a.dk_rs = a.dv_rs = 3 * E
+            grads = (dqkv, None, None)
+        else:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+            a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
+            a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+            a.dq_bs, a.dk_bs, a.dv_bs, a.dq_rs, a.dk_rs, a.dv_rs = Tq * E, Tk * E, Tk * E, E, E, E
+            grads = (dq, dk, dv)
+        a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd)
+        a.out, a.out_rs, a.stats, a.d_out = out.data_ptr(), E, stats.data_ptr(), dout.data_ptr()
+        a.drop_p, a.rng, a.layer = drop_p, _p(rng), layer
+        _ck(lib().ctdd_hollow_attention_bwd(C.byref(a), _st()), "ctdd_hollow_attention_bwd")
+        return grads + (None,) * 9
+
+
+# ---------------------------------------------------------------------- activation / dropout / add / embedding
+class ActFn(torch.autograd.Function):
+    """dropout(act(x)): act 1 ReLU, 2 GELU (erf)."""
+
+    @staticmethod
+    def forward(ctx, pre, act, drop_p, rng, layer):
+        pre = pre.contiguous()
+        out = torch.empty_like(pre)
+        _ck(lib().ctdd_hollow_act(pre.data_ptr(), None, out.data_ptr(), None, pre.numel(), act, float(drop_p), _p(rng), int(layer), _st()),
+            "ctdd_hollow_act")
+        ctx.save_for_backward(pre, rng)
+        ctx.meta = (act, float(drop_p), int(layer))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pre, rng = ctx.saved_tensors
+        act, drop_p, layer = ctx.meta
+        dout = dout.contiguous()
+        dpre = torch.empty_like(pre)
+        _ck(lib().ctdd_hollow_act(pre.data_ptr(), dout.data_ptr(), dpre.data_ptr(), None, pre.numel(), act, drop_p, _p(rng), layer, _st()),
+            "ctdd_hollow_act")
+        return dpre, None, None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop_p, rng, layer):
+        y = x.clone()
+        _ck(lib().ctdd_unet_dropout(y.data_ptr(), None, y.numel(), float(drop_p), rng.data_ptr(), int(layer), _st()), "ctdd_unet_dropout")
+        ctx.save_for_backward(rng)
+        ctx.meta = (float(drop_p), int(layer))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rng,) = ctx.saved_tensors
+        drop_p, layer = ctx.meta
+        dx = dy.clone()
+        _ck(lib().ctdd_unet_dropout(dx.data_ptr(), None, dx.numel(), drop_p, rng.data_ptr(), layer, _st()), "ctdd_unet_dropout")
+        return dx, None, None, None
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, q):
+        p, q = p.contiguous(), q.contiguous()
+        out = torch.empty_like(p)
+        n = p.numel()
+        _ck(lib().ctdd_hollow_add(p.data_ptr(), n, q.data_ptr(), n, out.data_ptr(), None, None, n, 1, n, _st()), "ctdd_hollow_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+class EmbedFn(torch.autograd.Function):
+    """(l2r, r2l, temb) token sequences from the integer state (hollow_networks.py:729-753)."""
+
+    @staticmethod
+    def forward(ctx, x, t, w_in, b_in, pe, S, temb_scale):
+        B, D = x.shape
+        E = w_in.numel()
+        dev = x.device
+        l2r, r2l, temb = (torch.empty((B, D, E), dtype=torch.float32, device=dev), torch.empty((B, D, E), dtype=torch.float32, device=dev),
+                          torch.empty((B, E), dtype=torch.float32, device=dev))
+        x = x.contiguous()
+        a = _EmbedArgs()
+        if x.dtype == torch.int64:
+            a.x64 = x.data_ptr()
+        else:
+            a.x32 = x.data_ptr()
+        wv, bv, tv = w_in.detach().reshape(-1).contiguous(), b_in.detach().contiguous(), t.float().contiguous()
+        a.t, a.w_in, a.b_in, a.pe = tv.data_ptr(), wv.data_ptr(), bv.data_ptr(), pe.data_ptr()
+        a.B, a.D, a.E, a.S, a.temb_scale = B, D, E, S, float(temb_scale)
+        a.l2r, a.r2l, a.temb = l2r.data_ptr(), r2l.data_ptr(), temb.data_ptr()
+        _ck(lib().ctdd_hollow_embed(C.byref(a), _st()), "ctdd_hollow_embed")
+        ctx.save_for_backward(x)
+        ctx.meta = (S, w_in.shape)
+        ctx.mark_non_differentiable(temb)
+        return l2r, r2l, temb
+
+    @staticmethod
+    def backward(ctx, dl2r, dr2l, _dtemb):
+        (x,) = ctx.saved_tensors
+        S, wshape = ctx.meta
+        B, D = x.shape
+        E = dl2r.shape[-1]
+        dl2r, dr2l = dl2r.contiguous(), dr2l.contiguous()
+        dw = torch.zeros((E,), dtype=torch.float32, device=x.device)
+        db = torch.zeros((E,), dtype=torch.float32, device=x.device)
+        a = _EmbedBwdArgs()
+        if x.dtype == torch.int64:
+            a.x64 = x.data_ptr()
+        else:
+            a.x32 = x.data_ptr()
+        a.dl2r, a.dr2l, a.B, a.D, a.E, a.S, a.dw, a.db = dl2r.data_ptr(), dr2l.data_ptr(), B, D, E, S, dw.data_ptr(), db.data_ptr()
+        _ck(lib().ctdd_hollow_embed_bwd(C.byref(a), _st()), "ctdd_hollow_embed_bwd")
+        return None, None, dw.view(wshape), db, None, None, None
+
+
+# ---------------------------------------------------------------------- the network
+def training_supported(model):
+    net = _unwrap(getattr(model, "net", None))
+    if net is None or getattr(net.config.model, "engine_train", "hip") != "hip" or not supports(model):
+        return False
+    m = net.config.model
+    return (m.embed_dim // m.num_heads) in (4, 8, 16, 32) and m.embed_dim <= 256 and m.embed_dim % 16 == 0 and m.mlp_dim % 16 == 0
+
+
+class HollowTrainer:
+    def __init__(self, model, precision=None):
+        self.model, self.net = model, _unwrap(model.net)
+        m = self.net.config.model
+        self.precision = precision or getattr(m, "engine_train_precision", "bf16")
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"unknown training precision {self.precision}")
+        self.dev = next(self.net.parameters()).device
+        if self.dev.type != "cuda":
+            raise native.CtddError("HollowTrainer needs the model on a GPU")
+        lib()
+        self.rng = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self.rng[0] = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        self.pe = None
+
+    def __call__(self, x, times):
+        net = self.net
+        m = net.config.model
+        bf = self.precision == "bf16"
+        E, H, S = m.embed_dim, m.num_heads, net.S
+        hd = E // H
+        B, D = x.shape
+        training = bool(self.model.training)
+        p_drop = float(m.dropout_rate) if training else 0.0
+        p_att = float(m.attention_dropout_rate) if training else 0.0
+        if training:
+            self.rng[1] += 1                                  # one dropout stream per training forward
+        rng = self.rng
+        layer = [0]
+
+        def nxt():
+            layer[0] += 1
+            return layer[0]
+
+        def drop(t, p):
+            return DropoutFn.apply(t, p, rng, nxt()) if p > 0.0 else t
+
+        if self.pe is None or self.pe.shape[0] < D:
+            self.pe = net.module_l2r.pos_embed.pe[0, :D].to(self.dev).float().contiguous()
+        l2r, r2l, temb = EmbedFn.apply(x, times, net.input_embedding.weight, net.input_embedding.bias, self.pe, S, float(net.temb_scale))
+        R = B * D
+        streams = []
+        for seq, stack, mode in ((l2r, net.module_l2r, 0), (r2l, net.module_r2l, 1)):
+            h = drop(drop(seq, p_drop), p_drop)               # PositionalEncoding's dropout, then the stack's (hollow_networks.py:562-563)
+            for blk in stack.trans_block_layers:
+                sa, ff = blk.self_attention_block, blk.feed_forward_block
+                mha = sa.self_attention
+                z = LayerNormFn.apply(h, None, sa.norm.weight, sa.norm.bias, None, sa.norm.eps)
+                qkv = linear(z.view(R, E), mha.in_proj_weight, mha.in_proj_bias, bf)
+                ctxv = AttentionFn.apply(qkv, None, None, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, nxt())
+                if p_drop > 0.0:
+                    o = linear(ctxv, mha.out_proj.weight, mha.out_proj.bias, bf)
+                    h = AddFn.apply(drop(o, p_drop).view(B, D, E), h)
+                else:
+                    h = linear(ctxv, mha.out_proj.weight, mha.out_proj.bias, bf, res=h.reshape(R, E)).view(B, D, E)
+                z = LayerNormFn.apply(h, None, ff.norm.weight, ff.norm.bias, None, ff.norm.eps)
+                u = linear(z.view(R, E), ff.mlp.fc1.weight, ff.mlp.fc1.bias, bf)
+                u = ActFn.apply(u, 1, p_drop, rng if p_drop > 0 else None, nxt())
+                if p_drop > 0.0:
+                    o = linear(u, ff.mlp.fc2.weight, None, bf)
+                    h = AddFn.apply(drop(o, p_drop).view(B, D, E), h)
+                else:
+                    h = linear(u, ff.mlp.fc2.weight, None, bf, res=h.reshape(R, E)).view(B, D, E)
+            streams.append(h)
+        l2r, r2l = streams
+        # ---- attention readout (prenorm): cross attention over [temb | ln1(l2r) | ln2(r2l)] + (l2r + r2l)
+        ro = net.readout_module
+        ca = ro.cross_attention
+        Tk = 2 * D + 1
+        a1 = LayerNormFn.apply(l2r, None, ro.ln1.weight, ro.ln1.bias, None, ro.ln1.eps)
+        a2 = LayerNormFn.apply(r2l, None, ro.ln2.weight, ro.ln2.bias, None, ro.ln2.eps)
+        allk = torch.cat([temb.unsqueeze(1), a1, a2], dim=1).reshape(B * Tk, E)
+        qin = AddFn.apply(a1, a2).view(R, E)
+        raw = AddFn.apply(l2r, r2l).view(R, E)
+        qb = linear(qin, ca.dense_query.weight, None, bf)
+        kb = linear(allk, ca.dense_key.weight, ca.dense_key.bias, bf)
+        vb = linear(allk, ca.dense_val.weight, ca.dense_val.bias, bf)
+        ctxv = AttentionFn.apply(qb, kb, vb, B, D, Tk, H, hd, 2, 0.0, None, nxt())
+        xr = linear(ctxv, ca.out_linear.weight, ca.out_linear.bias, bf, res=raw)
+        # ---- FiLM residual readout
+        rr = ro.model
+        E2 = 2 * E
+        lin = [l_ for l_ in rr.mlp.layers if isinstance(l_, torch.nn.Linear)]
+        tm = linear(ActFn.apply(linear(temb, lin[0].weight, lin[0].bias, False), 2, 0.0, None, 0), lin[1].weight, lin[1].bias, False)
+        hh = linear(xr, rr.input_layer.weight, rr.input_layer.bias, bf)
+        for i in range(rr.n_res):
+            mlp_i, ln_i = rr.resid_layers[2 * i], rr.resid_layers[2 * i + 1]
+            li = [l_ for l_ in mlp_i.layers if isinstance(l_, torch.nn.Linear)]
+            r_ = linear(ActFn.apply(linear(hh, li[0].weight, li[0].bias, bf), 2, 0.0, None, 0), li[1].weight, li[1].bias, bf)
+            fl = linear(tm, rr.film_layer[i].weight, rr.film_layer[i].bias, False)
+            hh = LayerNormFn.apply(hh.view(B, D, E2), r_.view(B, D, E2), ln_i.weight, ln_i.bias, fl, ln_i.eps).view(R, E2)
+        logits = linear(hh, rr.logits_layer.weight, rr.logits_layer.bias, bf)
+        return logits.view(B, D, rr.out_dim)

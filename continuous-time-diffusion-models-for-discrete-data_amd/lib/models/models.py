@@ -172,10 +172,11 @@ class HollowTransformer(nn.Module):
             raise ValueError(f"only nets='bidir_transformer2' is built (got {cfg.model.nets})")
         self.net = _maybe_ddp(net, cfg, rank)
         self.cfg = cfg
-        self._engine = None
+        self._engine, self._trainer = None, None
 
     def forward(self, x, times):
-        if self._use_engine(x):
+        mode = self._use_engine(x)
+        if mode == "infer":
             from ctdd import hollow_engine
             if self._engine is None:
                 # cfg.model.engine_precision: "bf16x3" (default; hi + lo bf16 operand pairs, three matrix-core products per
@@ -184,22 +185,39 @@ class HollowTransformer(nn.Module):
                 self._engine = hollow_engine.HollowEngine(self, precision=getattr(self.cfg.model, "engine_precision", None))
             out = self._engine(x, times)
             return out if getattr(self, "_borrow_engine_output", False) else out.clone()
+        if mode == "train":
+            from ctdd import hollow_train
+            if self._trainer is None:
+                # cfg.model.engine_train_precision: "bf16" (default: bf16 GEMM operands, fp32 accumulation / attention /
+                # LayerNorm / residual streams) or "fp32" (exact-fp32 matrix instructions: gradients to ~1e-5 of autograd's)
+                self._trainer = hollow_train.HollowTrainer(self)
+            inner = unwrap(self.net)
+            inner._engine_hook = self._trainer          # through DistributedDataParallel.forward when wrapped
+            try:
+                return self.net(x, times)
+            finally:
+                inner._engine_hook = None
         return self.net(x, times)
 
-    # -- hand-written HIP inference engine (ctdd/hollow_engine.py); training keeps autograd ops
+    # -- hand-written HIP engines: inference plan (ctdd/hollow_engine.py), training Functions (ctdd/hollow_train.py)
     def _use_engine(self, x):
         if getattr(self.cfg.model, "engine", "hip") != "hip" or not x.is_cuda:
-            return False
-        if torch.is_grad_enabled() or self.training:
-            return False
+            return None
         from ctdd import hollow_engine
         if x.dtype not in (torch.int64, torch.int32):
             _warn_once(self, "hollow-dtype", f"HIP engine takes integer states, got {x.dtype}; running torch device ops")
-            return False
+            return None
         if not hollow_engine.supports(self):
             _warn_once(self, "hollow", "hollow-transformer variant outside the HIP engine's coverage; running torch device ops")
-            return False
-        return True
+            return None
+        if torch.is_grad_enabled() or self.training:
+            from ctdd import hollow_train
+            if not hollow_train.training_supported(self):
+                if getattr(self.cfg.model, "engine_train", "hip") == "hip":
+                    _warn_once(self, "hollow-train", "hollow-transformer shape outside the HIP training kernels' coverage; running torch device ops")
+                return None
+            return "train"
+        return "infer"
 
 
 class EMA:

@@ -7,7 +7,7 @@ Token d of the output sees x_0..x_{d-1} through the left-to-right stack and x_{d
 the right-to-left stack, never x_d itself ("hollow"), so logits[d] parameterises
 p(x^d | x^{\\d}).  The module tree keeps the reference's parameter names (including the two
 sub-modules its forward never uses, `embedding` and `temb_net`) so checkpoints load unchanged.
-Device ops (autograd-capable); a hand-written inference engine for this network is future work.
+Device ops (autograd-capable); the HIP inference plan is ctdd/hollow_engine.py, the HIP training path ctdd/hollow_train.py.
 """
 import math
 
@@ -252,6 +252,9 @@ class BidirectionalTransformer2(nn.Module):
                                       nn.Linear(self.mlp_dim, self.embed_dim))    # unused by forward
 
     def forward(self, x, t):
+        hook = getattr(self, "_engine_hook", None)       # the HIP training path (ctdd/hollow_train.py), entered through
+        if hook is not None:                             # this forward so a DistributedDataParallel wrapper sees the call
+            return hook(x, t)
         temb = transformer_timestep_embedding(t * self.temb_scale, self.embed_dim)
         B, D = x.shape
         if self.use_cat:
