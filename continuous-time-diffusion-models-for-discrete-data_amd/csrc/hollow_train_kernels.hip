@@ -47,80 +47,109 @@ struct LnBwdArgs {
   float* dgamma; float* dbeta;                              // [E], atomically accumulated
   float* dfilm;                                             // [B][2E] (da | db), atomically accumulated, or null
 };
+// KN = ceil(E / 64) columns per lane; RG rows in flight per wave (independent loads and reduction chains overlap); the
+// four waves of a workgroup meet in LDS before ONE atomic per column and workgroup (thousands of waves on the same
+// 2E addresses serialise in L2 otherwise: 117 us -> ~15 us at 28800 x 128).
+template <int KN>
 __global__ __launch_bounds__(256) void k_hollow_ln_bwd(const LnBwdArgs a) {
-  const int lane = threadIdx.x & 63, E = a.E;
+  constexpr int RG = KN <= 2 ? 4 : 2;
+  __shared__ float red[4][2][64 * KN];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, E = a.E;
   const int wps = (a.T + a.rpw - 1) / a.rpw;                                  // waves per sample
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= (int64_t)a.B * wps) return;
-  const int b = (int)(w / wps), j0 = (int)(w % wps) * a.rpw, j1 = min(j0 + a.rpw, a.T);
-  float g[8], be[8], fa[8], fb[8], sg[8], sb[8], sa[8], sfb[8];
+  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
+  const bool live = w < (int64_t)a.B * wps;
+  const int b = live ? (int)(w / wps) : 0, j0 = live ? (int)(w % wps) * a.rpw : 0, j1 = live ? min(j0 + a.rpw, a.T) : 0;
+  float g[KN], be[KN], fa[KN], sg[KN], sb[KN], sa[KN], sfb[KN];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < KN; ++k) {
     const int e = lane + 64 * k;
     g[k] = e < E ? a.gamma[e] : 0.0f;
     be[k] = e < E ? a.beta[e] : 0.0f;
     fa[k] = (a.film && e < E) ? a.film[(size_t)b * a.film_stride + e] : 1.0f;
-    fb[k] = (a.film && e < E) ? a.film[(size_t)b * a.film_stride + E + e] : 0.0f;
     sg[k] = sb[k] = sa[k] = sfb[k] = 0.0f;
   }
-  (void)fb;
-  for (int j = j0; j < j1; ++j) {
-    const float* x = a.x + (size_t)b * a.x_bs + (size_t)j * E;
-    const float* y = a.y ? a.y + (size_t)b * a.y_bs + (size_t)j * E : nullptr;
-    const float* dr = a.dout + (size_t)b * a.dout_bs + (size_t)j * E;
-    float h[8], d[8];
-    float s = 0.0f;
+  for (int jb = j0; jb < j1; jb += RG) {
+    float h[RG][KN], d[RG][KN], s[RG], q[RG];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = lane + 64 * k;
-      h[k] = e < E ? x[e] + (y ? y[e] : 0.0f) : 0.0f;
-      d[k] = e < E ? dr[e] : 0.0f;
-      s += h[k];
+    for (int r = 0; r < RG; ++r) {
+      const int j = min(jb + r, j1 - 1);
+      const float* x = a.x + (size_t)b * a.x_bs + (size_t)j * E;
+      const float* y = a.y ? a.y + (size_t)b * a.y_bs + (size_t)j * E : nullptr;
+      const float* dr = a.dout + (size_t)b * a.dout_bs + (size_t)j * E;
+      s[r] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const int e = lane + 64 * k;
+        h[r][k] = e < E ? x[e] + (y ? y[e] : 0.0f) : 0.0f;
+        d[r][k] = (e < E && jb + r < j1) ? dr[e] : 0.0f;                       // rows past the run contribute nothing
+        s[r] += h[r][k];
+      }
     }
-    const float mean = hwave_sum(s) / (float)E;
-    float q = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float t = lane + 64 * k < E ? h[k] - mean : 0.0f;
-      q = fmaf(t, t, q);
+    for (int r = 0; r < RG; ++r) s[r] = hwave_sum(s[r]) / (float)E;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      q[r] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const float t = lane + 64 * k < E ? h[r][k] - s[r] : 0.0f;
+        q[r] = fmaf(t, t, q[r]);
+      }
     }
-    const float rstd = 1.0f / sqrtf(hwave_sum(q) / (float)E + a.eps);
-    float m1 = 0.0f, m2 = 0.0f, xh[8], dxh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool on = lane + 64 * k < E;
-      xh[k] = on ? (h[k] - mean) * rstd : 0.0f;
-      const float z = g[k] * xh[k] + be[k];
-      const float dz = d[k] * fa[k];
-      sa[k] += d[k] * z; sfb[k] += d[k];
-      sg[k] = fmaf(dz, xh[k], sg[k]); sb[k] += dz;
-      dxh[k] = on ? dz * g[k] : 0.0f;
-      m1 += dxh[k]; m2 = fmaf(dxh[k], xh[k], m2);
+    for (int r = 0; r < RG; ++r) q[r] = 1.0f / sqrtf(hwave_sum(q[r]) / (float)E + a.eps);
+    float m1[RG], m2[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      m1[r] = m2[r] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const bool on = lane + 64 * k < E;
+        const float xh = on ? (h[r][k] - s[r]) * q[r] : 0.0f;
+        const float z = g[k] * xh + be[k];
+        const float dz = d[r][k] * fa[k];
+        sa[k] = fmaf(d[r][k], z, sa[k]); sfb[k] += d[r][k];
+        sg[k] = fmaf(dz, xh, sg[k]); sb[k] += dz;
+        const float dxh = on ? dz * g[k] : 0.0f;
+        h[r][k] = xh; d[r][k] = dxh;                                          // reuse the registers: xhat, dxhat
+        m1[r] += dxh; m2[r] = fmaf(dxh, xh, m2[r]);
+      }
     }
-    m1 = hwave_sum(m1) / (float)E; m2 = hwave_sum(m2) / (float)E;
-    float* dx = a.dx + (size_t)b * a.dx_bs + (size_t)j * E;
-    float* dy = (a.dy && a.y) ? a.dy + (size_t)b * a.dy_bs + (size_t)j * E : nullptr;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = lane + 64 * k;
-      if (e < E) {
-        const float v = rstd * (dxh[k] - m1 - xh[k] * m2);
-        dx[e] = a.acc_dx ? dx[e] + v : v;
-        if (dy) dy[e] = a.acc_dy ? dy[e] + v : v;
+    for (int r = 0; r < RG; ++r) { m1[r] = hwave_sum(m1[r]) / (float)E; m2[r] = hwave_sum(m2[r]) / (float)E; }
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      if (jb + r >= j1) break;
+      const int j = jb + r;
+      float* dx = a.dx + (size_t)b * a.dx_bs + (size_t)j * E;
+      float* dy = (a.dy && a.y) ? a.dy + (size_t)b * a.dy_bs + (size_t)j * E : nullptr;
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const int e = lane + 64 * k;
+        if (e < E) {
+          const float v = q[r] * (d[r][k] - m1[r] - h[r][k] * m2[r]);
+          dx[e] = a.acc_dx ? dx[e] + v : v;
+          if (dy) dy[e] = a.acc_dy ? dy[e] + v : v;
+        }
       }
     }
   }
+  if (a.dfilm && live) {                                                       // per-sample sums: few waves per address
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int e = lane + 64 * k;
-    if (e < E) {
-      atomicAdd(a.dgamma + e, sg[k]);
-      atomicAdd(a.dbeta + e, sb[k]);
-      if (a.dfilm) {
+    for (int k = 0; k < KN; ++k) {
+      const int e = lane + 64 * k;
+      if (e < E) {
         atomicAdd(a.dfilm + (size_t)b * 2 * E + e, sa[k]);
         atomicAdd(a.dfilm + (size_t)b * 2 * E + E + e, sfb[k]);
       }
     }
+  }
+#pragma unroll
+  for (int k = 0; k < KN; ++k) { red[wv][0][lane + 64 * k] = sg[k]; red[wv][1][lane + 64 * k] = sb[k]; }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * 64 * KN; idx += 256) {
+    const int which = idx / (64 * KN), e = idx % (64 * KN);
+    if (e < E) atomicAdd((which ? a.dbeta : a.dgamma) + e, red[0][which][e] + red[1][which][e] + red[2][which][e] + red[3][which][e]);
   }
 }
 
@@ -135,6 +164,8 @@ struct AttnTrainArgs {
   float drop_p; const uint64_t* rng; uint64_t layer;
   // backward
   const float* d_out; float* dq; float* dk; float* dv; int64_t dq_bs, dk_bs, dv_bs; int dq_rs, dk_rs, dv_rs;
+  // optional bf16 copies (the matrix-core kernels): of out (forward), of dq / dk / dv (same strides as the fp32 ones)
+  unsigned short* out_bf16; unsigned short* dq_bf16; unsigned short* dk_bf16; unsigned short* dv_bf16;
 };
 __device__ inline bool attn_allowed(int mode, int Tq, int i, int j) {
   if (mode == 0) return j <= i;
@@ -304,6 +335,316 @@ __global__ __launch_bounds__(TQ) void k_hollow_attn_bwd_kv(const AttnTrainArgs a
   }
 }
 
+// ============================================================================ training attention on the matrix cores (bf16 operands)
+// Same contract and the same Philox masks as the fp32 kernels above, head dimensions 16 and 32; the products run on
+// v_mfma_f32_32x32x16_bf16, softmax / dropout / dS in fp32.  Register layout as k_hollow_attention_mfma (hollow_kernels.hip):
+// a 32 x 32 accumulator tile puts ONE column on a lane (two lanes, halves kh = 0 / 1, per column) and rows
+// (r & 3) + 8 (r >> 2) + 4 kh in its registers r = 0..15 -- which, packed to bf16, IS the B operand of a product contracting over
+// those rows (with the A operand read from LDS in the same row order), so no tile ever moves between lanes:
+//   forward / dQ kernel  (wave = 32 queries, lane = query):  S^T = K Q^T,  dP^T = V dO^T,  O^T += V^T P^T,  dQ^T += K^T dS^T
+//   dK / dV kernel       (wave = 32 keys,    lane = key):    S = Q K^T,    dP = dO V^T,    dV^T += dO^T P,  dK^T += Q^T dS
+using bf16x8t = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16t = __attribute__((ext_vector_type(16))) float;
+using u32x4t = __attribute__((ext_vector_type(4))) unsigned;
+__device__ inline unsigned ht_pack2(float a, float b) {
+  using v2f = __attribute__((ext_vector_type(2))) float;
+  using v2b = __attribute__((ext_vector_type(2))) __bf16;
+  v2f v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));
+}
+// B-operand fragments of one row of a [.][HD] fp32 matrix (the lane's query or key): dims 16 s + 8 kh .. + 7 of k-step s
+template <int HD>
+__device__ inline void row_frags(const float* row, bool ok, float scale, int kh, bf16x8t (&f)[HD / 16]) {
+#pragma unroll
+  for (int s_ = 0; s_ < HD / 16; ++s_) {
+    float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0;
+    if (ok) { u0 = *(const float4*)(row + 16 * s_ + 8 * kh); u1 = *(const float4*)(row + 16 * s_ + 8 * kh + 4); }
+    f[s_] = __builtin_bit_cast(bf16x8t, u32x4t{ht_pack2(u0.x * scale, u0.y * scale), ht_pack2(u0.z * scale, u0.w * scale),
+                                               ht_pack2(u1.x * scale, u1.y * scale), ht_pack2(u1.z * scale, u1.w * scale)});
+  }
+}
+// does the chunk of 32 keys from jc concern the queries [lo, hi]?  /  does every (query, key) pair of the two ranges pass the mask?
+__device__ inline bool chunk_any(int mode, int Tq, int Tk, int jc, int lo, int hi) {
+  const int jl = min(jc + 32, Tk) - 1;
+  if (hi < lo || jc >= Tk) return false;
+  if (mode == 0) return jc <= hi;
+  if (mode == 1) return jl >= lo;
+  return jc == 0 || (jc <= Tq && jc - 1 <= hi) || (jl > Tq && jl - Tq - 1 >= lo);
+}
+__device__ inline bool chunk_full(int mode, int Tq, int Tk, int j0, int q0) {   // queries q0..q0+31, keys j0..j0+31, all in range
+  if (q0 + 31 >= Tq || j0 + 31 >= Tk) return false;
+  if (mode == 0) return j0 + 31 <= q0;
+  if (mode == 1) return j0 >= q0 + 31;
+  return (j0 >= 1 && j0 + 31 <= Tq && j0 + 30 <= q0) || (j0 > Tq && j0 - Tq - 1 >= q0 + 31);
+}
+constexpr int RLD16 = 8, TLD = 40;                  // row-major rows: HD + 8 bf16; transposed rows: 32 + 8
+
+// stage 32 rows [row][HD] of an fp32 matrix as bf16: row-major into R (when given) and transposed [dim][row] into T (when given)
+template <int HD>
+__device__ inline void stage32(const float* base, int64_t rs, int r0, int rmax, float scale, unsigned short* R, unsigned short* T) {
+  constexpr int RLD = HD + RLD16;
+  if (threadIdx.x < 32 * HD / 4) {
+    const int rr = threadIdx.x / (HD / 4), c4 = (threadIdx.x % (HD / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + rr < rmax) v = *(const float4*)(base + (size_t)(r0 + rr) * rs + c4);
+    const unsigned p01 = ht_pack2(v.x * scale, v.y * scale), p23 = ht_pack2(v.z * scale, v.w * scale);
+    if (R) *(uint2*)(R + rr * RLD + c4) = make_uint2(p01, p23);
+    if (T) {
+      T[(c4 + 0) * TLD + rr] = (unsigned short)(p01 & 0xFFFFu); T[(c4 + 1) * TLD + rr] = (unsigned short)(p01 >> 16);
+      T[(c4 + 2) * TLD + rr] = (unsigned short)(p23 & 0xFFFFu); T[(c4 + 3) * TLD + rr] = (unsigned short)(p23 >> 16);
+    }
+  }
+}
+// A operand of a product contracting over the 32 staged rows, from a transposed tile: lane = dim column, rows in register order
+__device__ inline bf16x8t tfrag(const unsigned short* T, int col, int kh, int s_) {
+  const unsigned short* p = T + col * TLD + 16 * s_ + 4 * kh;
+  const uint2 a = *(const uint2*)p, b = *(const uint2*)(p + 8);
+  return __builtin_bit_cast(bf16x8t, u32x4t{a.x, a.y, b.x, b.y});
+}
+
+// MODE_BWD false: forward with dropout, writes out (+ bf16 copy) and the row statistics;  true: D_i = dO.O and dQ
+template <int HD, bool BWD>
+__global__ __launch_bounds__(256) void k_hollow_attn_q_mfma(const AttnTrainArgs a) {
+  constexpr int KS = HD / 16, RLD = HD + RLD16;
+  __shared__ __attribute__((aligned(16))) unsigned short Kr[32 * RLD];          // K rows [key][dim]
+  __shared__ __attribute__((aligned(16))) unsigned short Vr[BWD ? 32 * RLD : 8];   // V rows (backward: dP^T = V dO^T)
+  __shared__ __attribute__((aligned(16))) unsigned short Tt[32 * TLD];          // forward: V^T;  backward: K^T   ([dim][key], dims >= HD zero)
+  const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int q0 = blockIdx.x * 128 + wave * 32, i = q0 + col;
+  const bool qok = i < a.Tq;
+  bf16x8t qf[KS], dof[KS];
+  row_frags<HD>(a.q + (size_t)b * a.q_bs + (size_t)(qok ? i : 0) * a.q_rs + h * HD, qok, a.scale, kh, qf);
+  float m = BWD ? 0.0f : -INFINITY, l = 0.0f, inv_l = 0.0f, Di = 0.0f;
+  float* st = a.stats + (((size_t)b * a.H + h) * a.Tq + (qok ? i : 0)) * 4;
+  if (BWD) {
+    const float* dr = a.d_out + ((size_t)b * a.Tq + (qok ? i : 0)) * a.out_rs + h * HD;
+    const float* orow = a.out + ((size_t)b * a.Tq + (qok ? i : 0)) * a.out_rs + h * HD;
+    row_frags<HD>(dr, qok, 1.0f, kh, dof);
+    if (qok) {
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) Di = fmaf(dr[16 * s_ + 8 * kh + c], orow[16 * s_ + 8 * kh + c], Di);
+      m = st[0]; inv_l = 1.0f / st[1];
+    }
+    Di += __shfl_xor(Di, 32, WAVE);
+    if (qok && kh == 0) st[2] = Di;
+  }
+  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
+  const uint64_t qrow = (((uint64_t)b * a.H + h) * a.Tq + (qok ? i : 0)) * quads;
+  f32x16t oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
+  for (int idx = threadIdx.x; idx < 32 * TLD / 2; idx += 256) ((unsigned*)Tt)[idx] = 0u;   // (rows >= HD stay zero)
+  const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tq) - 1, mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;
+  const float* kb = a.k + (size_t)b * a.k_bs + h * HD;
+  const float* vb = a.v + (size_t)b * a.v_bs + h * HD;
+  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+    if (!chunk_any(a.mode, a.Tq, a.Tk, j0, wlo, whi)) continue;                 // (uniform over the workgroup)
+    __syncthreads();
+    stage32<HD>(kb, a.k_rs, j0, a.Tk, 1.0f, Kr, BWD ? Tt : nullptr);
+    stage32<HD>(vb, a.v_rs, j0, a.Tk, 1.0f, BWD ? Vr : nullptr, BWD ? nullptr : Tt);
+    __syncthreads();
+    if (!chunk_any(a.mode, a.Tq, a.Tk, j0, mylo, myhi)) continue;               // (wave-uniform; no barrier below)
+    f32x16t sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const bf16x8t kf = *(const bf16x8t*)(Kr + col * RLD + 16 * s_ + 8 * kh);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], sacc, 0, 0, 0);
+      if (BWD) {
+        const bf16x8t vf = *(const bf16x8t*)(Vr + col * RLD + 16 * s_ + 8 * kh);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s_], pacc, 0, 0, 0);
+      }
+    }
+    const bool full = chunk_full(a.mode, a.Tq, a.Tk, j0, q0);
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const bool ok = qok && j < a.Tk && attn_allowed(a.mode, a.Tq, i, j);
+        sacc[r] = ok ? sacc[r] : -INFINITY;
+      }
+    }
+    unsigned keep = 0xFFFFu;                                                     // bit r: probability r survives the dropout
+    if (a.drop_p > 0.0f) {
+      keep = 0u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) keep |= keep4(a.rng, a.layer, qrow + (uint64_t)((j0 + 8 * g + 4 * kh) >> 2), a.drop_p) << (4 * g);
+    }
+    unsigned pw[8];
+    if (!BWD) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+      const float mn = fmaxf(m, mx);
+      const float msafe = mn == -INFINITY ? 0.0f : mn;
+      const float corr = __expf(m - msafe);
+      float rs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __expf(sacc[r] - msafe), p1 = __expf(sacc[r + 1] - msafe);
+        rs += p0 + p1;
+        pw[r >> 1] = ht_pack2((keep >> r) & 1u ? p0 * inv_keep : 0.0f, (keep >> (r + 1)) & 1u ? p1 * inv_keep : 0.0f);
+      }
+      rs += __shfl_xor(rs, 32, WAVE);
+      l = l * corr + rs;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= corr;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __expf(sacc[r] - m) * inv_l, p1 = __expf(sacc[r + 1] - m) * inv_l;       // exp(-inf) = 0 for masked pairs
+        const float d0 = (keep >> r) & 1u ? pacc[r] * inv_keep : 0.0f, d1 = (keep >> (r + 1)) & 1u ? pacc[r + 1] * inv_keep : 0.0f;
+        pw[r >> 1] = ht_pack2(p0 * (d0 - Di), p1 * (d1 - Di));
+      }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const bf16x8t pf = __builtin_bit_cast(bf16x8t, u32x4t{pw[4 * s_], pw[4 * s_ + 1], pw[4 * s_ + 2], pw[4 * s_ + 3]});
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Tt, col, kh, s_), pf, oacc, 0, 0, 0);
+    }
+  }
+  if (!qok) return;
+  if (!BWD && kh == 0) { st[0] = m; st[1] = l; }
+  const float f = BWD ? a.scale : 1.0f / l;
+  const size_t oo = BWD ? (size_t)b * a.dq_bs + (size_t)i * a.dq_rs + h * HD : ((size_t)b * a.Tq + i) * a.out_rs + h * HD;
+  float* o32 = BWD ? a.dq : a.out;
+  unsigned short* o16 = BWD ? a.dq_bf16 : a.out_bf16;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int d0 = 8 * r4 + 4 * kh;                                            // dims d0..d0+3 = registers 4 r4 .. 4 r4 + 3
+    if (d0 < HD) {
+      const float4 v = make_float4(oacc[4 * r4] * f, oacc[4 * r4 + 1] * f, oacc[4 * r4 + 2] * f, oacc[4 * r4 + 3] * f);
+      if (o32) *(float4*)(o32 + oo + d0) = v;
+      if (o16) *(uint2*)(o16 + oo + d0) = make_uint2(ht_pack2(v.x, v.y), ht_pack2(v.z, v.w));
+    }
+  }
+}
+
+// dK, dV: wave = 32 keys (lane = key), loop over chunks of 32 queries
+template <int HD>
+__global__ __launch_bounds__(256) void k_hollow_attn_kv_mfma(const AttnTrainArgs a) {
+  constexpr int KS = HD / 16, RLD = HD + RLD16;
+  __shared__ __attribute__((aligned(16))) unsigned short Qr[32 * RLD], Dr[32 * RLD];     // scale Q rows, dO rows  [query][dim]
+  __shared__ __attribute__((aligned(16))) unsigned short Qt[32 * TLD], Dt[32 * TLD];     // their transposes [dim][query]
+  __shared__ float Sm[32], Sl[32], Sd[32];                                                // per query: max, 1 / sum, D_i
+  const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kh = lane >> 5;
+  const int k0 = blockIdx.x * 128 + wave * 32, j = k0 + col;
+  const bool kok = j < a.Tk;
+  bf16x8t kf[KS], vf[KS];
+  row_frags<HD>(a.k + (size_t)b * a.k_bs + (size_t)(kok ? j : 0) * a.k_rs + h * HD, kok, 1.0f, kh, kf);
+  row_frags<HD>(a.v + (size_t)b * a.v_bs + (size_t)(kok ? j : 0) * a.v_rs + h * HD, kok, 1.0f, kh, vf);
+  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
+  f32x16t kacc, vacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { kacc[r] = 0.0f; vacc[r] = 0.0f; }
+  for (int idx = threadIdx.x; idx < 32 * TLD / 2; idx += 256) { ((unsigned*)Qt)[idx] = 0u; ((unsigned*)Dt)[idx] = 0u; }
+  const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tk) - 1, mylo = k0, myhi = min(k0 + 32, a.Tk) - 1;
+  // does the chunk of queries i0.. see any key of [lo, hi]?  (the mask read from the key side)
+  auto q_any = [&](int i0, int lo, int hi) {
+    const int il = min(i0 + 32, a.Tq) - 1;
+    if (hi < lo) return false;
+    if (a.mode == 0) return lo <= il;                                          // j <= i for some pair
+    if (a.mode == 1) return hi >= i0;
+    if (lo == 0) return true;
+    const bool first = lo <= a.Tq && lo - 1 <= il;                             // keys 1..Tq: j - 1 <= i
+    const bool second = hi > a.Tq && hi - a.Tq - 1 >= i0;                      // keys Tq+1..: j - Tq - 1 >= i
+    return first || second;
+  };
+  const float* qb = a.q + (size_t)b * a.q_bs + h * HD;
+  const float* db = a.d_out + (size_t)b * a.Tq * a.out_rs + h * HD;
+  const float* sb = a.stats + ((size_t)b * a.H + h) * a.Tq * 4;
+  for (int i0 = 0; i0 < a.Tq; i0 += 32) {
+    if (!q_any(i0, wlo, whi)) continue;                                         // (uniform over the workgroup)
+    __syncthreads();
+    stage32<HD>(qb, a.q_rs, i0, a.Tq, a.scale, Qr, Qt);
+    stage32<HD>(db, a.out_rs, i0, a.Tq, 1.0f, Dr, Dt);
+    if (threadIdx.x < 32) {
+      const int i = i0 + threadIdx.x;
+      const bool ok = i < a.Tq;
+      Sm[threadIdx.x] = ok ? sb[(size_t)i * 4] : 0.0f;
+      Sl[threadIdx.x] = ok ? 1.0f / sb[(size_t)i * 4 + 1] : 0.0f;
+      Sd[threadIdx.x] = ok ? sb[(size_t)i * 4 + 2] : 0.0f;
+    }
+    __syncthreads();
+    if (!q_any(i0, mylo, myhi)) continue;                                       // (wave-uniform; no barrier below)
+    f32x16t sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.0f; pacc[r] = 0.0f; }
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const bf16x8t qa = *(const bf16x8t*)(Qr + col * RLD + 16 * s_ + 8 * kh);
+      const bf16x8t da = *(const bf16x8t*)(Dr + col * RLD + 16 * s_ + 8 * kh);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s_], sacc, 0, 0, 0);       // S[query][key]
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s_], pacc, 0, 0, 0);       // dP[query][key]
+    }
+    unsigned keep = 0xFFFFu;                                                     // bit r: probability (query r, this key) survives
+    if (a.drop_p > 0.0f) {
+      // the Philox block of (query, four consecutive keys) serves four neighbouring lanes: lane computes the blocks of the
+      // registers r = 4 g + (col & 3) and the four exchange them
+      unsigned mine = 0u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = i0 + (col & 3) + 8 * g + 4 * kh;
+        const uint64_t quad = (((uint64_t)b * a.H + h) * a.Tq + (uint64_t)min(i, a.Tq - 1)) * quads + (uint64_t)(min(j, a.Tk - 1) >> 2);
+        mine |= keep4(a.rng, a.layer, quad, a.drop_p) << (4 * g);
+      }
+      keep = 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned w = (unsigned)__shfl((int)mine, (lane & ~3) | u, WAVE);  // blocks of the registers 4 g + u
+#pragma unroll
+        for (int g = 0; g < 4; ++g) keep |= ((w >> (4 * g + (j & 3))) & 1u) << (4 * g + u);
+      }
+    }
+    unsigned pw[8], dw[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      float p[2], ds[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int il = ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * kh, i = i0 + il;
+        const bool ok = kok && i < a.Tq && attn_allowed(a.mode, a.Tq, i, j);
+        const float pr = ok ? __expf(sacc[r + e] - Sm[il]) * Sl[il] : 0.0f;
+        const bool kp = (keep >> (r + e)) & 1u;
+        p[e] = kp ? pr * inv_keep : 0.0f;
+        ds[e] = pr * ((kp ? pacc[r + e] * inv_keep : 0.0f) - Sd[il]);
+      }
+      pw[r >> 1] = ht_pack2(p[0], p[1]);
+      dw[r >> 1] = ht_pack2(ds[0], ds[1]);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const bf16x8t pf = __builtin_bit_cast(bf16x8t, u32x4t{pw[4 * s_], pw[4 * s_ + 1], pw[4 * s_ + 2], pw[4 * s_ + 3]});
+      const bf16x8t df = __builtin_bit_cast(bf16x8t, u32x4t{dw[4 * s_], dw[4 * s_ + 1], dw[4 * s_ + 2], dw[4 * s_ + 3]});
+      vacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Dt, col, kh, s_), pf, vacc, 0, 0, 0);   // dV^T += dO^T P
+      kacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfrag(Qt, col, kh, s_), df, kacc, 0, 0, 0);   // dK^T += (scale Q)^T dS
+    }
+  }
+  if (!kok) return;
+  const size_t ok_ = (size_t)b * a.dk_bs + (size_t)j * a.dk_rs + h * HD, ov = (size_t)b * a.dv_bs + (size_t)j * a.dv_rs + h * HD;
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int d0 = 8 * r4 + 4 * kh;
+    if (d0 < HD) {
+      const float4 kv = make_float4(kacc[4 * r4], kacc[4 * r4 + 1], kacc[4 * r4 + 2], kacc[4 * r4 + 3]);
+      const float4 vv = make_float4(vacc[4 * r4], vacc[4 * r4 + 1], vacc[4 * r4 + 2], vacc[4 * r4 + 3]);
+      if (a.dk) *(float4*)(a.dk + ok_ + d0) = kv;
+      if (a.dv) *(float4*)(a.dv + ov + d0) = vv;
+      if (a.dk_bf16) *(uint2*)(a.dk_bf16 + ok_ + d0) = make_uint2(ht_pack2(kv.x, kv.y), ht_pack2(kv.z, kv.w));
+      if (a.dv_bf16) *(uint2*)(a.dv_bf16 + ov + d0) = make_uint2(ht_pack2(vv.x, vv.y), ht_pack2(vv.z, vv.w));
+    }
+  }
+}
+
 // ============================================================================ activation (+ dropout), forward and backward
 // forward: out = drop(act(pre)); backward: dpre = drop(dout) act'(pre).  act 0 none, 1 ReLU, 2 GELU (erf).  n % 4 == 0.
 __global__ __launch_bounds__(256) void k_hollow_act(const float* __restrict__ pre, const float* __restrict__ dout, float* __restrict__ out,
@@ -328,11 +669,8 @@ __global__ __launch_bounds__(256) void k_hollow_act(const float* __restrict__ pr
       const float kf = (keep >> k) & 1u ? inv_keep : 0.0f;
       r[k] = dout ? g[k] * kf * df : f * kf;
     }
-    *(float4*)(out + v * 4) = make_float4(r[0], r[1], r[2], r[3]);
-    if (out_bf16) {
-      unsigned short* o = out_bf16 + v * 4;
-      o[0] = ht_bf16(r[0]); o[1] = ht_bf16(r[1]); o[2] = ht_bf16(r[2]); o[3] = ht_bf16(r[3]);
-    }
+    if (out) *(float4*)(out + v * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    if (out_bf16) *(uint2*)(out_bf16 + v * 4) = make_uint2(ht_pack2(r[0], r[1]), ht_pack2(r[2], r[3]));
   }
 }
 
@@ -364,9 +702,12 @@ extern "C" int ctdd_hollow_layernorm_bwd(const void* args_, void* stream) {
   LnBwdArgs a = *(const LnBwdArgs*)args_;
   CTDD_REQUIRE(a.x && a.gamma && a.beta && a.dout && a.dx && a.dgamma && a.dbeta, CTDD_EINVAL, "layernorm bwd: null buffer");
   CTDD_REQUIRE(a.E >= 1 && a.E <= 512 && a.B > 0 && a.T > 0, CTDD_ERANGE, "layernorm bwd: E=%d (<= 512) B=%d T=%d", a.E, a.B, a.T);
-  if (a.rpw <= 0) a.rpw = 8;
+  if (a.rpw <= 0) a.rpw = 16;
   const int64_t waves = (int64_t)a.B * ((a.T + a.rpw - 1) / a.rpw);
-  hipLaunchKernelGGL(k_hollow_ln_bwd, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  if (a.E <= 128) hipLaunchKernelGGL(k_hollow_ln_bwd<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (a.E <= 256) hipLaunchKernelGGL(k_hollow_ln_bwd<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_hollow_ln_bwd<8>, grid, dim3(256), 0, (hipStream_t)stream, a);
   return finish_launch("k_hollow_ln_bwd");
 }
 
@@ -401,9 +742,37 @@ extern "C" int ctdd_hollow_attention_bwd(const void* args_, void* stream) {
 }
 #undef HD_DISPATCH
 
+#define HD_DISPATCH_MFMA(KERNEL16, KERNEL32, GRIDX)                                                          \
+  if (a.hd == 16) hipLaunchKernelGGL(KERNEL16, dim3(GRIDX, a.H, a.B), dim3(256), 0, (hipStream_t)stream, a); \
+  else hipLaunchKernelGGL(KERNEL32, dim3(GRIDX, a.H, a.B), dim3(256), 0, (hipStream_t)stream, a);
+static int attn_check_mfma(const AttnTrainArgs& a) {
+  if (int rc = attn_check(a)) return rc;
+  CTDD_REQUIRE(a.hd == 16 || a.hd == 32, CTDD_ERANGE, "attention (training, matrix cores): head dimension %d (16 or 32)", a.hd);
+  CTDD_REQUIRE(a.q_rs % 4 == 0 && a.k_rs % 4 == 0 && a.v_rs % 4 == 0 && a.out_rs % 4 == 0 && a.q_bs % 4 == 0 && a.k_bs % 4 == 0 && a.v_bs % 4 == 0,
+               CTDD_EINVAL, "attention (training, matrix cores): rows must be 16-byte aligned");
+  return CTDD_OK;
+}
+extern "C" int ctdd_hollow_attention_train_bf16(const void* args_, void* stream) {
+  const AttnTrainArgs& a = *(const AttnTrainArgs*)args_;
+  if (int rc = attn_check_mfma(a)) return rc;
+  HD_DISPATCH_MFMA((k_hollow_attn_q_mfma<16, false>), (k_hollow_attn_q_mfma<32, false>), (a.Tq + 127) / 128)
+  return finish_launch("k_hollow_attn_q_mfma (forward)");
+}
+extern "C" int ctdd_hollow_attention_bwd_bf16(const void* args_, void* stream) {
+  const AttnTrainArgs& a = *(const AttnTrainArgs*)args_;
+  if (int rc = attn_check_mfma(a)) return rc;
+  CTDD_REQUIRE(a.d_out && (a.dq || a.dq_bf16) && (a.dk || a.dk_bf16) && (a.dv || a.dv_bf16), CTDD_EINVAL, "attention bwd: null gradient buffer");
+  CTDD_REQUIRE(a.dq_rs % 4 == 0 && a.dk_rs % 4 == 0 && a.dv_rs % 4 == 0 && a.dq_bs % 4 == 0 && a.dk_bs % 4 == 0 && a.dv_bs % 4 == 0, CTDD_EINVAL,
+               "attention bwd (matrix cores): gradient rows must be 16-byte aligned");
+  HD_DISPATCH_MFMA((k_hollow_attn_q_mfma<16, true>), (k_hollow_attn_q_mfma<32, true>), (a.Tq + 127) / 128)
+  if (int rc = finish_launch("k_hollow_attn_q_mfma (dQ)")) return rc;
+  HD_DISPATCH_MFMA((k_hollow_attn_kv_mfma<16>), (k_hollow_attn_kv_mfma<32>), (a.Tk + 127) / 128)
+  return finish_launch("k_hollow_attn_kv_mfma");
+}
+
 extern "C" int ctdd_hollow_act(const float* pre, const float* dout, float* out, void* out_bf16, int64_t n, int act, float drop_p,
                                const uint64_t* rng, uint64_t layer, void* stream) {
-  CTDD_REQUIRE(pre && out && n > 0 && n % 4 == 0 && act >= 0 && act <= 2, CTDD_EINVAL, "act: n=%lld act=%d", (long long)n, act);
+  CTDD_REQUIRE(pre && (out || out_bf16) && n > 0 && n % 4 == 0 && act >= 0 && act <= 2, CTDD_EINVAL, "act: n=%lld act=%d", (long long)n, act);
   CTDD_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && (drop_p == 0.0f || rng), CTDD_EINVAL, "act: dropout %g", (double)drop_p);
   int64_t g = (n / 4 + 255) / 256;
   if (g > 8192) g = 8192;

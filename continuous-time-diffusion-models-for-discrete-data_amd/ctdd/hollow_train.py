@@ -40,7 +40,8 @@ class _AttnTrainArgs(C.Structure):
     _fields_ = [("q", _P), ("k", _P), ("v", _P), ("q_bs", _I64), ("k_bs", _I64), ("v_bs", _I64), ("q_rs", _I), ("k_rs", _I), ("v_rs", _I),
                 ("B", _I), ("Tq", _I), ("Tk", _I), ("H", _I), ("hd", _I), ("mode", _I), ("scale", _F), ("out", _P), ("out_rs", _I),
                 ("stats", _P), ("drop_p", _F), ("rng", _P), ("layer", _U64), ("d_out", _P), ("dq", _P), ("dk", _P), ("dv", _P),
-                ("dq_bs", _I64), ("dk_bs", _I64), ("dv_bs", _I64), ("dq_rs", _I), ("dk_rs", _I), ("dv_rs", _I)]
+                ("dq_bs", _I64), ("dk_bs", _I64), ("dv_bs", _I64), ("dq_rs", _I), ("dk_rs", _I), ("dv_rs", _I),
+                ("out_bf16", _P), ("dq_bf16", _P), ("dk_bf16", _P), ("dv_bf16", _P)]
 
 
 class _EmbedBwdArgs(C.Structure):
@@ -56,7 +57,8 @@ def lib():
     unet_train.lib()
     if not _sigs_done:
         for name, argt in (("ctdd_hollow_layernorm_bwd", [_P, _P]), ("ctdd_hollow_attention_train", [_P, _P]),
-                           ("ctdd_hollow_attention_bwd", [_P, _P]),
+                           ("ctdd_hollow_attention_bwd", [_P, _P]), ("ctdd_hollow_attention_train_bf16", [_P, _P]),
+                           ("ctdd_hollow_attention_bwd_bf16", [_P, _P]),
                            ("ctdd_hollow_act", [_P, _P, _P, _P, _I64, _I, _F, _P, _U64, _P]), ("ctdd_hollow_embed_bwd", [_P, _P])):
             fn = getattr(l, name)
             fn.argtypes, fn.restype = argt, _I
@@ -77,11 +79,14 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-# ---------------------------------------------------------------------- GEMM on the implicit-GEMM kernels
-def _gemm(x, w, bias, res, rows, K, N, bf16):
-    """out[rows][N] (fp32) = x[rows][K] @ w[N][K]^T (+ bias) (+ res).  x, w: fp32, or bf16 when `bf16`."""
+# ---------------------------------------------------------------------- launch helpers (no autograd)
+def _gemm(x, w, bias, res, rows, K, N, bf16, act=0, want_hi=False, want_f32=True):
+    """out[rows][N] = act(x[rows][K] @ w[N][K]^T (+ bias)) (+ res) -> (fp32 out or None, bf16 copy or None).
+    x, w: fp32, or bf16 when `bf16`."""
     l = lib()
-    out = torch.empty((rows, N), dtype=torch.float32, device=x.device)
+    dev = x.device
+    out = torch.empty((rows, N), dtype=torch.float32, device=dev) if want_f32 else None
+    out_hi = torch.empty((rows, N), dtype=torch.bfloat16, device=dev) if want_hi else None
     a = _ConvArgs()
     a.nseg = 1
     a.seg[0].C, a.seg[0].kind = K, SEG_1x1
@@ -90,7 +95,7 @@ def _gemm(x, w, bias, res, rows, K, N, bf16):
     else:
         a.seg[0].f32, a.w_f32 = x.data_ptr(), w.data_ptr()
     a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = 1, rows, 1, rows, 1, N, K
-    a.bias, a.res_f32, a.out_f32 = _p(bias), _p(res), out.data_ptr()
+    a.bias, a.res_f32, a.out_f32, a.out_hi, a.act = _p(bias), _p(res), _p(out), _p(out_hi), act
     if bf16 and N % 8 == 0:
         pbk = 64 if K % 64 == 0 else 48 if K % 48 == 0 else 32 if K % 32 == 0 else 16
         if pbk == 64:
@@ -109,7 +114,7 @@ def _gemm(x, w, bias, res, rows, K, N, bf16):
         bk = 32 if K % 32 == 0 else 16
         bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
         _ck(l.ctdd_unet_conv(C.byref(a), bk, bnt, 1, _st()), "ctdd_unet_conv")
-    return out
+    return out, out_hi
 
 
 def _cast(x, rows, n, ld_out, bf16):
@@ -120,7 +125,23 @@ def _cast(x, rows, n, ld_out, bf16):
     return out
 
 
-_tables = {}
+def _w_op(w, bf16):
+    """[N][K] weight as the forward GEMM's operand."""
+    return w.detach().to(torch.bfloat16).contiguous() if bf16 else w.detach().contiguous()
+
+
+def _wt_op(w, bf16, ld=None):
+    """[K][ld] transposed weight (columns >= N zero): the data-gradient GEMM's operand."""
+    N, K = w.shape
+    dt = torch.bfloat16 if bf16 else torch.float32
+    if ld is None or ld == N:
+        return w.detach().t().to(dt).contiguous()
+    wt = torch.zeros((K, ld), dtype=dt, device=w.device)
+    wt[:, :N] = w.detach().t()
+    return wt
+
+
+_tables, _ones_cache = {}, {}
 
 
 def _device_table(raw, dev):
@@ -129,9 +150,17 @@ def _device_table(raw, dev):
     key = (raw, dev.index)
     t = _tables.get(key)
     if t is None:
-        if len(_tables) > 4096:
+        if len(_tables) > 8192:
             _tables.clear()
         t = _tables[key] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    return t
+
+
+def _ones(rows, bf16, dev):
+    key = (rows, bf16, dev.index)
+    t = _ones_cache.get(key)
+    if t is None:
+        t = _ones_cache[key] = torch.ones((rows, 8), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
     return t
 
 
@@ -146,17 +175,167 @@ def _wgrad_geometry(rows, N, K, bf16, budget=144 * 1024):
     raise native.CtddError("weight gradient: no chunk fits the kernel's staging slots")
 
 
+def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias):
+    """dW[N][K] = dY^T X (tokens are the contraction index) and, with `bias`, db[N] = column sums of dY as one more entry
+    of the same table launch (a weight gradient against an all-ones input of eight columns)."""
+    dev = dy_op.device
+    dw = torch.zeros((N, K), dtype=torch.float32, device=dev)
+    dbs = torch.zeros((N, 8), dtype=torch.float32, device=dev) if bias else None
+    ents = []
+    for xs, gw, Kc in ((x_op, dw, K),) + (((_ones(rows, bf16, dev), dbs, 8),) if bias else ()):
+        a = unet_train._WgradArgs()
+        a.x, a.dy, a.gw = xs.data_ptr(), dy_op.data_ptr(), gw.data_ptr()
+        a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind = 1, rows, 1, rows, 1, N, ld, Kc, Kc, 0, unet_train.WG_1x1
+        a.nwn, a.nlr = _wgrad_geometry(rows, N, Kc, bf16)
+        a.nchunks = -(-rows // a.nlr)
+        groups = -(-N // (32 * a.nwn)) * -(-Kc // (32 * (4 // a.nwn)))
+        a.grid_x, a.tap = max(1, min(a.nchunks, -(-768 // groups))), 0
+        ents.append(a)
+    tab = (unet_train._WgradArgs * len(ents))(*ents)
+    _ck(lib().ctdd_unet_wgrad(_device_table(bytes(tab), dev).data_ptr(), C.addressof(tab), len(ents), 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
+    return dw, (dbs[:, 0] if bias else None)
+
+
+def _layernorm(x, y, gamma, beta, film, eps, want_f32=True, want_hi=False):
+    B, T, E = x.shape
+    out = torch.empty_like(x) if want_f32 else None
+    out_hi = torch.empty((B, T, E), dtype=torch.bfloat16, device=x.device) if want_hi else None
+    a = _LnArgs()
+    a.x, a.y, a.x_bs, a.y_bs, a.out_bs = x.data_ptr(), _p(y), T * E, T * E, T * E
+    a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+    a.film, a.film_stride, a.B, a.T, a.E, a.out = _p(film), 0 if film is None else film.shape[1], B, T, E, _p(out)
+    a.out_hi, a.out_hi_bs = _p(out_hi), T * E
+    _ck(lib().ctdd_hollow_layernorm(C.byref(a), _st()), "ctdd_hollow_layernorm")
+    return out, out_hi
+
+
+def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dx=None):
+    """-> (dx, dgamma, dbeta, dfilm); with `dx` given the gradient is ADDED into it (the residual stream's gradient)."""
+    B, T, E = x.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+    dfilm = None if film is None else torch.zeros_like(film)
+    a = _LnBwdArgs()
+    a.x, a.y, a.x_bs, a.y_bs = x.data_ptr(), _p(y), T * E, T * E
+    a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+    a.film, a.film_stride = _p(film), 0 if film is None else film.shape[1]
+    a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 16
+    a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, int(acc)
+    a.dgamma, a.dbeta, a.dfilm = dg.data_ptr(), db.data_ptr(), _p(dfilm)
+    _ck(lib().ctdd_hollow_layernorm_bwd(C.byref(a), _st()), "ctdd_hollow_layernorm_bwd")
+    return dx, dg, db, dfilm
+
+
+def _attn_args(q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer):
+    E = H * hd
+    a = _AttnTrainArgs()
+    if k is None:                                       # packed qkv rows (B*T, 3E)
+        a.q, a.k, a.v = q.data_ptr(), q.data_ptr() + 4 * E, q.data_ptr() + 8 * E
+        a.q_bs = a.k_bs = a.v_bs = Tq * 3 * E
+        a.q_rs = a.k_rs = a.v_rs = 3 * E
+    else:
+        a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+        a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
+    a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd)
+    a.out_rs, a.drop_p, a.rng, a.layer = E, float(drop_p), _p(rng), int(layer)
+    return a
+
+
+def _attention_fwd(q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer, bf16):
+    """-> (ctx fp32 (B*Tq, E), bf16 copy or None, stats)."""
+    E = H * hd
+    dev = q.device
+    out = torch.empty((B * Tq, E), dtype=torch.float32, device=dev)
+    stats = torch.empty((B, H, Tq, 4), dtype=torch.float32, device=dev)
+    a = _attn_args(q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer)
+    a.out, a.stats = out.data_ptr(), stats.data_ptr()
+    if bf16 and hd in (16, 32):
+        out_hi = torch.empty((B * Tq, E), dtype=torch.bfloat16, device=dev)
+        a.out_bf16 = out_hi.data_ptr()
+        _ck(lib().ctdd_hollow_attention_train_bf16(C.byref(a), _st()), "ctdd_hollow_attention_train_bf16")
+        return out, out_hi, stats
+    _ck(lib().ctdd_hollow_attention_train(C.byref(a), _st()), "ctdd_hollow_attention_train")
+    return out, (_cast(out, B * Tq, E, E, True) if bf16 else None), stats
+
+
+def _attention_bwd(q, k, v, out, stats, dout, B, Tq, Tk, H, hd, mode, drop_p, rng, layer, bf16, want_f32=True):
+    """-> (dq, dk, dv) fp32 (dqkv, None, None for packed rows) and their bf16 copies when the matrix-core kernels ran."""
+    E = H * hd
+    mfma = bf16 and hd in (16, 32)
+    a = _attn_args(q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer)
+    a.out, a.stats, a.d_out = out.data_ptr(), stats.data_ptr(), dout.data_ptr()
+    f32 = want_f32 or not mfma
+    hi = [None, None, None]
+    if k is None:
+        dqkv = torch.empty_like(q) if f32 else None
+        if f32:
+            a.dq, a.dk, a.dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * E, dqkv.data_ptr() + 8 * E
+        a.dq_bs = a.dk_bs = a.dv_bs = Tq * 3 * E
+        a.dq_rs = a.dk_rs = a.dv_rs = 3 * E
+        if mfma:
+            hi[0] = torch.empty(q.shape, dtype=torch.bfloat16, device=q.device)
+            a.dq_bf16, a.dk_bf16, a.dv_bf16 = hi[0].data_ptr(), hi[0].data_ptr() + 2 * E, hi[0].data_ptr() + 4 * E
+        grads = (dqkv, None, None)
+    else:
+        grads = tuple(torch.empty_like(t) if f32 else None for t in (q, k, v))
+        if f32:
+            a.dq, a.dk, a.dv = (g.data_ptr() for g in grads)
+        a.dq_bs, a.dk_bs, a.dv_bs, a.dq_rs, a.dk_rs, a.dv_rs = Tq * E, Tk * E, Tk * E, E, E, E
+        if mfma:
+            hi = [torch.empty(t.shape, dtype=torch.bfloat16, device=t.device) for t in (q, k, v)]
+            a.dq_bf16, a.dk_bf16, a.dv_bf16 = (t.data_ptr() for t in hi)
+    if mfma:
+        _ck(lib().ctdd_hollow_attention_bwd_bf16(C.byref(a), _st()), "ctdd_hollow_attention_bwd_bf16")
+    else:
+        _ck(lib().ctdd_hollow_attention_bwd(C.byref(a), _st()), "ctdd_hollow_attention_bwd")
+    return grads, hi
+
+
+def _act(pre, dout, act, drop_p, rng, layer, want_f32=True, want_hi=False):
+    out = torch.empty_like(pre) if want_f32 else None
+    out_hi = torch.empty(pre.shape, dtype=torch.bfloat16, device=pre.device) if want_hi else None
+    _ck(lib().ctdd_hollow_act(pre.data_ptr(), _p(dout), _p(out), _p(out_hi), pre.numel(), act, float(drop_p), _p(rng), int(layer), _st()),
+        "ctdd_hollow_act")
+    return out, out_hi
+
+
+def _dropout_(x, p, rng, layer):
+    _ck(lib().ctdd_unet_dropout(x.data_ptr(), None, x.numel(), float(p), rng.data_ptr(), int(layer), _st()), "ctdd_unet_dropout")
+    return x
+
+
+def _add(p, q):
+    out = torch.empty_like(p)
+    n = p.numel()
+    _ck(lib().ctdd_hollow_add(p.data_ptr(), n, q.data_ptr(), n, out.data_ptr(), None, None, n, 1, n, _st()), "ctdd_hollow_add")
+    return out
+
+
+def _linear_bwd(x_op, w, dy, rows, bf16, has_bias, need_dx=True, dy_hi=None):
+    """Gradients of y = x W^T + b given dy (fp32, or its bf16 copy dy_hi): (dx fp32, dW, db)."""
+    N, K = w.shape
+    ld = -(-N // 16) * 16
+    if bf16 and dy_hi is not None and ld == N:
+        dy_op = dy_hi
+    else:
+        dy_op = _cast(dy, rows, N, ld, bf16) if (bf16 or ld != N) else dy
+    dw, db = _wgrad(x_op, dy_op, rows, N, ld, K, bf16, has_bias)
+    dx = _gemm(dy_op, _wt_op(w, bf16, ld), None, None, rows, ld, K, bf16)[0] if need_dx else None
+    return dx, dw, db
+
+
+# ---------------------------------------------------------------------- autograd Functions
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b (+ res); x (rows, K) fp32."""
 
     @staticmethod
     def forward(ctx, x, w, b, res, bf16):
         rows, K = x.shape
-        N = w.shape[0]
         x = x.contiguous()
         xo = _cast(x, rows, K, K, True) if bf16 else x
-        wo = w.detach().to(torch.bfloat16).contiguous() if bf16 else w.detach().contiguous()
-        out = _gemm(xo, wo, None if b is None else b.detach(), None if res is None else res.contiguous(), rows, K, N, bf16)
+        out, _ = _gemm(xo, _w_op(w, bf16), None if b is None else b.detach(), None if res is None else res.contiguous(), rows, K, w.shape[0], bf16)
         ctx.save_for_backward(xo, w)
         ctx.bf16, ctx.has_b, ctx.has_res = bf16, b is not None, res is not None
         return out
@@ -164,36 +343,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xo, w = ctx.saved_tensors
-        bf16 = ctx.bf16
-        rows, K = xo.shape
-        N = w.shape[0]
-        l = lib()
         dy = dy.contiguous()
-        ld = -(-N // 16) * 16
-        dyo = _cast(dy, rows, N, ld, bf16) if (bf16 or ld != N) else dy
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            # data gradient: the same GEMM with the transposed weight [K][ld] (columns >= N zero)
-            wt = torch.zeros((K, ld), dtype=dyo.dtype, device=dy.device)
-            wt[:, :N] = w.detach().t().to(dyo.dtype)
-            dx = _gemm(dyo, wt, None, None, rows, ld, K, bf16)
-        if ctx.needs_input_grad[1]:
-            dw = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
-            a = unet_train._WgradArgs()
-            a.x, a.dy, a.gw = xo.data_ptr(), dyo.data_ptr(), dw.data_ptr()
-            a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind = 1, rows, 1, rows, 1, N, ld, K, K, 0, unet_train.WG_1x1
-            a.nwn, a.nlr = _wgrad_geometry(rows, N, K, bf16)
-            a.nchunks = -(-rows // a.nlr)
-            groups = -(-N // (32 * a.nwn)) * -(-K // (32 * (4 // a.nwn)))
-            a.grid_x, a.tap = max(1, min(a.nchunks, -(-768 // groups))), 0
-            tab = (unet_train._WgradArgs * 1)(a)
-            _ck(l.ctdd_unet_wgrad(_device_table(bytes(tab), dy.device).data_ptr(), C.addressof(tab), 1, 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
-        if ctx.has_b and ctx.needs_input_grad[2]:
-            n8 = -(-N // 8) * 8
-            tmp = torch.zeros((n8,), dtype=torch.float32, device=dy.device)
-            _ck(l.ctdd_unet_colsum(None if bf16 else dyo.data_ptr(), dyo.data_ptr() if bf16 else None, 1, rows, n8, ld, None, 0, tmp.data_ptr(),
-                                   _st()), "ctdd_unet_colsum")
-            db = tmp[:N]
+        dx, dw, db = _linear_bwd(xo, w, dy, xo.shape[0], ctx.bf16, ctx.has_b and ctx.needs_input_grad[2], need_dx=ctx.needs_input_grad[0])
         return dx, dw, db, (dy if ctx.has_res else None), None
 
 
@@ -201,21 +352,14 @@ def linear(x, lin_w, lin_b, bf16, res=None):
     return LinearFn.apply(x, lin_w, lin_b, res, bf16)
 
 
-# ---------------------------------------------------------------------- LayerNorm (+ add, + FiLM)
 class LayerNormFn(torch.autograd.Function):
     """out = FiLM_b(LayerNorm(x (+ y))): x, y (B, T, E) contiguous; film (B, 2E) or None."""
 
     @staticmethod
     def forward(ctx, x, y, gamma, beta, film, eps):
-        B, T, E = x.shape
         x = x.contiguous()
         y = None if y is None else y.contiguous()
-        out = torch.empty_like(x)
-        a = _LnArgs()
-        a.x, a.y, a.x_bs, a.y_bs, a.out_bs = x.data_ptr(), _p(y), T * E, T * E, T * E
-        a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
-        a.film, a.film_stride, a.B, a.T, a.E, a.out = _p(film), 0 if film is None else film.shape[1], B, T, E, out.data_ptr()
-        _ck(lib().ctdd_hollow_layernorm(C.byref(a), _st()), "ctdd_hollow_layernorm")
+        out, _ = _layernorm(x, y, gamma, beta, film, eps)
         ctx.save_for_backward(x, y, gamma, beta, film)
         ctx.eps = float(eps)
         return out
@@ -223,90 +367,118 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, y, gamma, beta, film = ctx.saved_tensors
-        B, T, E = x.shape
-        dout = dout.contiguous()
-        dx = torch.empty_like(x)
-        dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
-        dfilm = None if film is None else torch.zeros_like(film)
-        a = _LnBwdArgs()
-        a.x, a.y, a.x_bs, a.y_bs = x.data_ptr(), _p(y), T * E, T * E
-        a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), ctx.eps
-        a.film, a.film_stride = _p(film), 0 if film is None else film.shape[1]
-        a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 8
-        a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, 0
-        a.dgamma, a.dbeta, a.dfilm = dg.data_ptr(), db.data_ptr(), _p(dfilm)
-        _ck(lib().ctdd_hollow_layernorm_bwd(C.byref(a), _st()), "ctdd_hollow_layernorm_bwd")
+        dx, dg, db, dfilm = _layernorm_bwd(x, y, gamma, beta, film, ctx.eps, dout.contiguous())
         return dx, (dx if y is not None else None), dg, db, dfilm, None
 
 
-# ---------------------------------------------------------------------- attention
 class AttentionFn(torch.autograd.Function):
     """Masked multi-head attention softmax(q k^T / sqrt(hd)) v with dropout on the probabilities.
     self-attention: qkv (B*T, 3E) with k = None;  readout: q (B*Tq, E), k, v (B*Tk, E)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer):
-        E = H * hd
+    def forward(ctx, q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer, bf16=False):
         q = q.contiguous()
-        out = torch.empty((B * Tq, E), dtype=torch.float32, device=q.device)
-        stats = torch.empty((B, H, Tq, 4), dtype=torch.float32, device=q.device)
-        a = _AttnTrainArgs()
-        if k is None:                                   # packed qkv rows
-            a.q, a.k, a.v = q.data_ptr(), q.data_ptr() + 4 * E, q.data_ptr() + 8 * E
-            a.q_bs = a.k_bs = a.v_bs = Tq * 3 * E
-            a.q_rs = a.k_rs = a.v_rs = 3 * E
-        else:
+        if k is not None:
             k, v = k.contiguous(), v.contiguous()
-            a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
-            a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
-        a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd)
-        a.out, a.out_rs, a.stats = out.data_ptr(), E, stats.data_ptr()
-        a.drop_p, a.rng, a.layer = float(drop_p), _p(rng), int(layer)
-        _ck(lib().ctdd_hollow_attention_train(C.byref(a), _st()), "ctdd_hollow_attention_train")
+        out, _, stats = _attention_fwd(q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer, bf16)
         ctx.save_for_backward(q, k, v, out, stats, rng)
-        ctx.meta = (B, Tq, Tk, H, hd, mode, float(drop_p), int(layer))
+        ctx.meta = (B, Tq, Tk, H, hd, mode, float(drop_p), int(layer), bf16)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, stats, rng = ctx.saved_tensors
-        B, Tq, Tk, H, hd, mode, drop_p, layer = ctx.meta
-        E = H * hd
-        dout = dout.contiguous()
-        a = _AttnTrainArgs()
-        if k is None:
-            dqkv = torch.empty_like(q)
-            a.q, a.k, a.v = q.data_ptr(), q.data_ptr() + 4 * E, q.data_ptr() + 8 * E
-            a.q_bs = a.k_bs = a.v_bs = Tq * 3 * E
-            a.q_rs = a.k_rs = a.v_rs = 3 * E
-            a.dq, a.dk, a.dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * E, dqkv.data_ptr() + 8 * E
-            a.dq_bs = a.dk_bs = a.dv_bs = Tq * 3 * E
-            a.dq_rs = a.dk_rs = a.dv_rs = 3 * E
-            grads = (dqkv, None, None)
+        B, Tq, Tk, H, hd, mode, drop_p, layer, bf16 = ctx.meta
+        grads, _ = _attention_bwd(q, k, v, out, stats, dout.contiguous(), B, Tq, Tk, H, hd, mode, drop_p, rng, layer, bf16)
+        return grads + (None,) * 10
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """h + dropout(out_proj(attention(in_proj(LayerNorm(h))))): one prenorm self-attention block (hollow_networks.py:311-340)
+    with a hand-scheduled backward: bf16 operand copies come out of the producing kernels, the residual stream's gradient
+    is accumulated by the LayerNorm backward."""
+
+    @staticmethod
+    def forward(ctx, h, ln_w, ln_b, w_in, b_in, w_out, b_out, rng, meta):
+        B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps = meta
+        E, R = H * hd, B * D
+        h = h.contiguous()
+        z, z_hi = _layernorm(h, None, ln_w, ln_b, None, eps, want_f32=not bf16, want_hi=bf16)
+        z_op = (z_hi if bf16 else z).view(R, E)
+        qkv, _ = _gemm(z_op, _w_op(w_in, bf16), b_in.detach(), None, R, E, 3 * E, bf16)
+        att, att_hi, stats = _attention_fwd(qkv, None, None, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16)
+        att_op = att_hi if bf16 else att
+        if p_drop > 0.0:
+            o, _ = _gemm(att_op, _w_op(w_out, bf16), b_out.detach(), None, R, E, E, bf16)
+            out = _add(_dropout_(o, p_drop, rng, l_drop), h.view(R, E))
         else:
-            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
-            a.q_bs, a.k_bs, a.v_bs, a.q_rs, a.k_rs, a.v_rs = Tq * E, Tk * E, Tk * E, E, E, E
-            a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
-            a.dq_bs, a.dk_bs, a.dv_bs, a.dq_rs, a.dk_rs, a.dv_rs = Tq * E, Tk * E, Tk * E, E, E, E
-            grads = (dq, dk, dv)
-        a.B, a.Tq, a.Tk, a.H, a.hd, a.mode, a.scale = B, Tq, Tk, H, hd, mode, 1.0 / math.sqrt(hd)
-        a.out, a.out_rs, a.stats, a.d_out = out.data_ptr(), E, stats.data_ptr(), dout.data_ptr()
-        a.drop_p, a.rng, a.layer = drop_p, _p(rng), layer
-        _ck(lib().ctdd_hollow_attention_bwd(C.byref(a), _st()), "ctdd_hollow_attention_bwd")
-        return grads + (None,) * 9
+            out, _ = _gemm(att_op, _w_op(w_out, bf16), b_out.detach(), h.view(R, E), R, E, E, bf16)
+        ctx.save_for_backward(h, ln_w, ln_b, w_in, w_out, z_op, qkv, att, att_op, stats, rng)
+        ctx.meta = meta
+        return out.view(B, D, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, ln_w, ln_b, w_in, w_out, z_op, qkv, att, att_op, stats, rng = ctx.saved_tensors
+        B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps = ctx.meta
+        E, R = H * hd, B * D
+        dout = dout.contiguous()
+        do = _dropout_(dout.clone(), p_drop, rng, l_drop) if p_drop > 0.0 else dout
+        datt, dw_out, db_out = _linear_bwd(att_op, w_out, do.view(R, E), R, bf16, True)
+        (dqkv, _, _), hi = _attention_bwd(qkv, None, None, att, stats, datt, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16,
+                                          want_f32=False)
+        dz, dw_in, db_in = _linear_bwd(z_op, w_in, dqkv, R, bf16, True, dy_hi=hi[0])
+        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone())
+        return dh, dg, dbeta, dw_in, db_in, dw_out, db_out, None, None
 
 
-# ---------------------------------------------------------------------- activation / dropout / add / embedding
+class MlpBlockFn(torch.autograd.Function):
+    """h + dropout(fc2(dropout(relu(fc1(LayerNorm(h)))))): one prenorm feed-forward block (hollow_networks.py:343-420)."""
+
+    @staticmethod
+    def forward(ctx, h, ln_w, ln_b, w1, b1, w2, rng, meta):
+        B, D, E, p_drop, l1, l2, bf16, eps = meta
+        R, M = B * D, w1.shape[0]
+        h = h.contiguous()
+        z, z_hi = _layernorm(h, None, ln_w, ln_b, None, eps, want_f32=not bf16, want_hi=bf16)
+        z_op = (z_hi if bf16 else z).view(R, E)
+        if p_drop > 0.0:
+            pre, _ = _gemm(z_op, _w_op(w1, bf16), b1.detach(), None, R, E, M, bf16)
+            u, u_hi = _act(pre, None, 1, p_drop, rng, l1, want_f32=not bf16, want_hi=bf16)
+        else:
+            pre, u_hi = _gemm(z_op, _w_op(w1, bf16), b1.detach(), None, R, E, M, bf16, act=1, want_hi=bf16)     # relu(pre): same ReLU mask
+            u = pre
+        u_op = u_hi if bf16 else u
+        if p_drop > 0.0:
+            o, _ = _gemm(u_op, _w_op(w2, bf16), None, None, R, M, E, bf16)
+            out = _add(_dropout_(o, p_drop, rng, l2), h.view(R, E))
+        else:
+            out, _ = _gemm(u_op, _w_op(w2, bf16), None, h.view(R, E), R, M, E, bf16)
+        ctx.save_for_backward(h, ln_w, ln_b, w1, w2, z_op, pre, u_op, rng)
+        ctx.meta = meta
+        return out.view(B, D, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, ln_w, ln_b, w1, w2, z_op, pre, u_op, rng = ctx.saved_tensors
+        B, D, E, p_drop, l1, l2, bf16, eps = ctx.meta
+        R = B * D
+        dout = dout.contiguous()
+        do = _dropout_(dout.clone(), p_drop, rng, l2) if p_drop > 0.0 else dout
+        du, dw2, _ = _linear_bwd(u_op, w2, do.view(R, E), R, bf16, False)
+        dpre, dpre_hi = _act(pre, du, 1, p_drop, rng if p_drop > 0 else None, l1, want_f32=not bf16, want_hi=bf16)
+        dz, dw1, db1 = _linear_bwd(z_op, w1, dpre, R, bf16, True, dy_hi=dpre_hi)
+        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone())
+        return dh, dg, dbeta, dw1, db1, dw2, None, None
+
+
 class ActFn(torch.autograd.Function):
     """dropout(act(x)): act 1 ReLU, 2 GELU (erf)."""
 
     @staticmethod
     def forward(ctx, pre, act, drop_p, rng, layer):
         pre = pre.contiguous()
-        out = torch.empty_like(pre)
-        _ck(lib().ctdd_hollow_act(pre.data_ptr(), None, out.data_ptr(), None, pre.numel(), act, float(drop_p), _p(rng), int(layer), _st()),
-            "ctdd_hollow_act")
+        out, _ = _act(pre, None, act, drop_p, rng, layer)
         ctx.save_for_backward(pre, rng)
         ctx.meta = (act, float(drop_p), int(layer))
         return out
@@ -315,39 +487,26 @@ class ActFn(torch.autograd.Function):
     def backward(ctx, dout):
         pre, rng = ctx.saved_tensors
         act, drop_p, layer = ctx.meta
-        dout = dout.contiguous()
-        dpre = torch.empty_like(pre)
-        _ck(lib().ctdd_hollow_act(pre.data_ptr(), dout.data_ptr(), dpre.data_ptr(), None, pre.numel(), act, drop_p, _p(rng), layer, _st()),
-            "ctdd_hollow_act")
-        return dpre, None, None, None, None
+        return _act(pre, dout.contiguous(), act, drop_p, rng, layer)[0], None, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, drop_p, rng, layer):
-        y = x.clone()
-        _ck(lib().ctdd_unet_dropout(y.data_ptr(), None, y.numel(), float(drop_p), rng.data_ptr(), int(layer), _st()), "ctdd_unet_dropout")
         ctx.save_for_backward(rng)
         ctx.meta = (float(drop_p), int(layer))
-        return y
+        return _dropout_(x.clone(), drop_p, rng, layer)
 
     @staticmethod
     def backward(ctx, dy):
         (rng,) = ctx.saved_tensors
-        drop_p, layer = ctx.meta
-        dx = dy.clone()
-        _ck(lib().ctdd_unet_dropout(dx.data_ptr(), None, dx.numel(), drop_p, rng.data_ptr(), layer, _st()), "ctdd_unet_dropout")
-        return dx, None, None, None
+        return _dropout_(dy.clone(), ctx.meta[0], rng, ctx.meta[1]), None, None, None
 
 
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, q):
-        p, q = p.contiguous(), q.contiguous()
-        out = torch.empty_like(p)
-        n = p.numel()
-        _ck(lib().ctdd_hollow_add(p.data_ptr(), n, q.data_ptr(), n, out.data_ptr(), None, None, n, 1, n, _st()), "ctdd_hollow_add")
-        return out
+        return _add(p.contiguous(), q.contiguous())
 
     @staticmethod
     def backward(ctx, d):
@@ -455,22 +614,10 @@ class HollowTrainer:
             for blk in stack.trans_block_layers:
                 sa, ff = blk.self_attention_block, blk.feed_forward_block
                 mha = sa.self_attention
-                z = LayerNormFn.apply(h, None, sa.norm.weight, sa.norm.bias, None, sa.norm.eps)
-                qkv = linear(z.view(R, E), mha.in_proj_weight, mha.in_proj_bias, bf)
-                ctxv = AttentionFn.apply(qkv, None, None, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, nxt())
-                if p_drop > 0.0:
-                    o = linear(ctxv, mha.out_proj.weight, mha.out_proj.bias, bf)
-                    h = AddFn.apply(drop(o, p_drop).view(B, D, E), h)
-                else:
-                    h = linear(ctxv, mha.out_proj.weight, mha.out_proj.bias, bf, res=h.reshape(R, E)).view(B, D, E)
-                z = LayerNormFn.apply(h, None, ff.norm.weight, ff.norm.bias, None, ff.norm.eps)
-                u = linear(z.view(R, E), ff.mlp.fc1.weight, ff.mlp.fc1.bias, bf)
-                u = ActFn.apply(u, 1, p_drop, rng if p_drop > 0 else None, nxt())
-                if p_drop > 0.0:
-                    o = linear(u, ff.mlp.fc2.weight, None, bf)
-                    h = AddFn.apply(drop(o, p_drop).view(B, D, E), h)
-                else:
-                    h = linear(u, ff.mlp.fc2.weight, None, bf, res=h.reshape(R, E)).view(B, D, E)
+                h = AttnBlockFn.apply(h, sa.norm.weight, sa.norm.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                                      mha.out_proj.bias, rng, (B, D, H, hd, mode, p_att, p_drop, nxt(), nxt(), bf, sa.norm.eps))
+                h = MlpBlockFn.apply(h, ff.norm.weight, ff.norm.bias, ff.mlp.fc1.weight, ff.mlp.fc1.bias, ff.mlp.fc2.weight, rng,
+                                     (B, D, E, p_drop, nxt(), nxt(), bf, ff.norm.eps))
             streams.append(h)
         l2r, r2l = streams
         # ---- attention readout (prenorm): cross attention over [temb | ln1(l2r) | ln2(r2l)] + (l2r + r2l)
@@ -485,7 +632,7 @@ class HollowTrainer:
         qb = linear(qin, ca.dense_query.weight, None, bf)
         kb = linear(allk, ca.dense_key.weight, ca.dense_key.bias, bf)
         vb = linear(allk, ca.dense_val.weight, ca.dense_val.bias, bf)
-        ctxv = AttentionFn.apply(qb, kb, vb, B, D, Tk, H, hd, 2, 0.0, None, nxt())
+        ctxv = AttentionFn.apply(qb, kb, vb, B, D, Tk, H, hd, 2, 0.0, None, nxt(), bf)
         xr = linear(ctxv, ca.out_linear.weight, ca.out_linear.bias, bf, res=raw)
         # ---- FiLM residual readout
         rr = ro.model

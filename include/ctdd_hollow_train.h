@@ -32,11 +32,16 @@ typedef struct {
   int B, Tq, Tk, H, hd, mode; float scale; float* out; int out_rs; float* stats;
   float drop_p; const uint64_t* rng; uint64_t layer;
   const float* d_out; float* dq; float* dk; float* dv; int64_t dq_bs, dk_bs, dv_bs; int dq_rs, dk_rs, dv_rs;
+  void* out_bf16; void* dq_bf16; void* dk_bf16; void* dv_bf16;   /* optional bf16 copies (the *_bf16 entry points), strides of the fp32 ones */
 } ctdd_hollow_attn_train_args;
 int ctdd_hollow_attention_train(const void* attn_train_args, void* stream);
 int ctdd_hollow_attention_bwd(const void* attn_train_args, void* stream);
+/* the same two on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 softmax / dropout / accumulation; head dimension 16 or 32;
+ * rows 16-byte aligned): identical Philox masks; out / dq / dk / dv may also (or only, for the gradients) be written as bf16 */
+int ctdd_hollow_attention_train_bf16(const void* attn_train_args, void* stream);
+int ctdd_hollow_attention_bwd_bf16(const void* attn_train_args, void* stream);
 
-/* dout == NULL: out = dropout(act(pre)) (+ bf16 copy);  dout != NULL: out = dropout(dout) * act'(pre).
+/* dout == NULL: out = dropout(act(pre)) (+ bf16 copy);  dout != NULL: out = dropout(dout) * act'(pre); out or out_bf16 may be NULL.
  * act 0 identity, 1 ReLU, 2 GELU (erf); n % 4 == 0 */
 int ctdd_hollow_act(const float* pre, const float* dout, float* out, void* out_bf16, int64_t n, int act, float drop_p,
                     const uint64_t* rng, uint64_t layer, void* stream);

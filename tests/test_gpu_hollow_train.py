@@ -181,6 +181,36 @@ def test_hollow_train_dropout_rate():
     assert not torch.equal(y != 0, y2 != 0)                      # another layer id, another mask
 
 
+@pytest.mark.parametrize("hd", [16, 32])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_hollow_attention_matrix_core_kernels_match_fp32_kernels(mode, hd, p):
+    """ctdd_hollow_attention_train_bf16 / _bwd_bf16 (v_mfma_f32_32x32x16_bf16) against the fp32 FMA kernels on the same
+    inputs and the SAME Philox dropout masks: maze-sized sequences (225 queries; 451 keys in the readout mode)."""
+    from ctdd.hollow_train import AttentionFn
+    torch.manual_seed(mode * 7 + hd)
+    B, D, H = 3, 225, 4
+    E = H * hd
+    Tk = 2 * D + 1 if mode == 2 else D
+    rng = torch.tensor([99, 5], dtype=torch.int64, device="cuda")
+    res = {}
+    if mode == 2:
+        base = [torch.randn((B * D, E), device="cuda"), torch.randn((B * Tk, E), device="cuda"), torch.randn((B * Tk, E), device="cuda")]
+    else:
+        base = [torch.randn((B * D, 3 * E), device="cuda")]
+    wgt = torch.randn((B * D, E), device="cuda")
+    for bf in (False, True):
+        ins = [t.clone().requires_grad_(True) for t in base]
+        q, k, v = (ins + [None, None])[:3]
+        out = AttentionFn.apply(q, k, v, B, D, Tk, H, hd, mode, p, rng if p > 0 else None, 4, bf)
+        (out * wgt).sum().backward()
+        res[bf] = [out.detach()] + [t.grad for t in ins]
+    for ref, got in zip(res[False], res[True]):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < 2e-2 * scale, (float((got - ref).abs().max()), scale)
+        assert float((got - ref).norm() / ref.norm()) < 6e-3
+
+
 def test_hollow_score_elbo_training_step_matches_torch():
     """One ScoreElbo training step (loss value, clipped-Adam update) through the model wrapper: HIP training path against
     the torch module, dropout 0 (maze hollow configuration at reduced depth)."""
