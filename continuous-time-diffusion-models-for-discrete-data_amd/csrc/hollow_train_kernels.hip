@@ -46,6 +46,7 @@ struct LnBwdArgs {
   float* dy; int64_t dy_bs; int acc_dy;
   float* dgamma; float* dbeta;                              // [E], atomically accumulated
   float* dfilm;                                             // [B][2E] (da | db), atomically accumulated, or null
+  int nrep; int rep_stride;                                 // > 1: workgroup w adds into dgamma / dbeta + (w % nrep) * rep_stride (the caller sums the replicas)
 };
 // KN = ceil(E / 64) columns per lane; RG rows in flight per wave (independent loads and reduction chains overlap); the
 // four waves of a workgroup meet in LDS before ONE atomic per column and workgroup (thousands of waves on the same
@@ -147,9 +148,11 @@ __global__ __launch_bounds__(256) void k_hollow_ln_bwd(const LnBwdArgs a) {
 #pragma unroll
   for (int k = 0; k < KN; ++k) { red[wv][0][lane + 64 * k] = sg[k]; red[wv][1][lane + 64 * k] = sb[k]; }
   __syncthreads();
+  const int rep = a.nrep > 1 ? (int)(blockIdx.x % (unsigned)a.nrep) : 0;
   for (int idx = threadIdx.x; idx < 2 * 64 * KN; idx += 256) {
     const int which = idx / (64 * KN), e = idx % (64 * KN);
-    if (e < E) atomicAdd((which ? a.dbeta : a.dgamma) + e, red[0][which][e] + red[1][which][e] + red[2][which][e] + red[3][which][e]);
+    if (e < E)
+      atomicAdd((which ? a.dbeta : a.dgamma) + (size_t)rep * a.rep_stride + e, red[0][which][e] + red[1][which][e] + red[2][which][e] + red[3][which][e]);
   }
 }
 

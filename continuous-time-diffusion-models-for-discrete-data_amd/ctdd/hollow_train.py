@@ -33,7 +33,8 @@ _P, _I, _F, _I64, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
 class _LnBwdArgs(C.Structure):
     _fields_ = [("x", _P), ("y", _P), ("x_bs", _I64), ("y_bs", _I64), ("gamma", _P), ("beta", _P), ("eps", _F), ("film", _P),
                 ("film_stride", _I), ("dout", _P), ("dout_bs", _I64), ("B", _I), ("T", _I), ("E", _I), ("rpw", _I), ("dx", _P),
-                ("dx_bs", _I64), ("acc_dx", _I), ("dy", _P), ("dy_bs", _I64), ("acc_dy", _I), ("dgamma", _P), ("dbeta", _P), ("dfilm", _P)]
+                ("dx_bs", _I64), ("acc_dx", _I), ("dy", _P), ("dy_bs", _I64), ("acc_dy", _I), ("dgamma", _P), ("dbeta", _P), ("dfilm", _P),
+                ("nrep", _I), ("rep_stride", _I)]
 
 
 class _AttnTrainArgs(C.Structure):
@@ -175,12 +176,13 @@ def _wgrad_geometry(rows, N, K, bf16, budget=144 * 1024):
     raise native.CtddError("weight gradient: no chunk fits the kernel's staging slots")
 
 
-def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias):
+def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias, bufs=None):
     """dW[N][K] = dY^T X (tokens are the contraction index) and, with `bias`, db[N] = column sums of dY as one more entry
-    of the same table launch (a weight gradient against an all-ones input of eight columns)."""
+    of the same table launch (a weight gradient against an all-ones input of eight columns).  bufs: zeroed (dW, [N][8])."""
     dev = dy_op.device
-    dw = torch.zeros((N, K), dtype=torch.float32, device=dev)
-    dbs = torch.zeros((N, 8), dtype=torch.float32, device=dev) if bias else None
+    if bufs is None:
+        bufs = _zeros(dev, (N, K), (N, 8)) if bias else (_zeros(dev, (N, K))[0], None)
+    dw, dbs = bufs
     ents = []
     for xs, gw, Kc in ((x_op, dw, K),) + (((_ones(rows, bf16, dev), dbs, 8),) if bias else ()):
         a = unet_train._WgradArgs()
@@ -209,23 +211,42 @@ def _layernorm(x, y, gamma, beta, film, eps, want_f32=True, want_hi=False):
     return out, out_hi
 
 
-def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dx=None):
-    """-> (dx, dgamma, dbeta, dfilm); with `dx` given the gradient is ADDED into it (the residual stream's gradient)."""
+LN_REPLICAS = 32
+
+
+def _zeros(dev, *shapes):
+    """fp32 zero tensors of the given shapes out of ONE fill."""
+    sizes = [int(math.prod(sh)) for sh in shapes]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    out, o = [], 0
+    for sh, n in zip(shapes, sizes):
+        out.append(flat[o:o + n].view(sh))
+        o += n
+    return out
+
+
+def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dx=None, rep=None):
+    """-> (dx, dgamma, dbeta, dfilm); with `dx` given the gradient is ADDED into it (the residual stream's gradient).
+    rep: zeroed (LN_REPLICAS, 2E) scratch for the replicated dgamma | dbeta accumulators."""
     B, T, E = x.shape
     acc = dx is not None
     if dx is None:
         dx = torch.empty_like(x)
-    dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+    if rep is None:
+        rep = torch.zeros((LN_REPLICAS, 2 * E), dtype=torch.float32, device=x.device)
     dfilm = None if film is None else torch.zeros_like(film)
     a = _LnBwdArgs()
     a.x, a.y, a.x_bs, a.y_bs = x.data_ptr(), _p(y), T * E, T * E
     a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
     a.film, a.film_stride = _p(film), 0 if film is None else film.shape[1]
-    a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 16
+    a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 4
     a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, int(acc)
-    a.dgamma, a.dbeta, a.dfilm = dg.data_ptr(), db.data_ptr(), _p(dfilm)
+    a.dgamma, a.dbeta, a.dfilm = rep.data_ptr(), rep.data_ptr() + 4 * E, _p(dfilm)
+    a.nrep, a.rep_stride = rep.shape[0], 2 * E
     _ck(lib().ctdd_hollow_layernorm_bwd(C.byref(a), _st()), "ctdd_hollow_layernorm_bwd")
-    return dx, dg, db, dfilm
+    gb = torch.empty((2 * E,), dtype=torch.float32, device=x.device)
+    _ck(lib().ctdd_unet_sum_batch(rep.data_ptr(), rep.shape[0], 2 * E, 1, 2 * E, gb.data_ptr(), 0, _st()), "ctdd_unet_sum_batch")
+    return dx, gb[:E], gb[E:], dfilm
 
 
 def _attn_args(q, k, v, B, Tq, Tk, H, hd, mode, drop_p, rng, layer):
@@ -313,16 +334,17 @@ def _add(p, q):
     return out
 
 
-def _linear_bwd(x_op, w, dy, rows, bf16, has_bias, need_dx=True, dy_hi=None):
-    """Gradients of y = x W^T + b given dy (fp32, or its bf16 copy dy_hi): (dx fp32, dW, db)."""
+def _linear_bwd(x_op, w, dy, rows, bf16, has_bias, need_dx=True, dy_hi=None, wt=None, bufs=None):
+    """Gradients of y = x W^T + b given dy (fp32, or its bf16 copy dy_hi): (dx fp32, dW, db).
+    wt: the packed transposed weight [K][ld] when the trainer prepared it; bufs: zeroed (dW, [N][8]) targets."""
     N, K = w.shape
     ld = -(-N // 16) * 16
     if bf16 and dy_hi is not None and ld == N:
         dy_op = dy_hi
     else:
         dy_op = _cast(dy, rows, N, ld, bf16) if (bf16 or ld != N) else dy
-    dw, db = _wgrad(x_op, dy_op, rows, N, ld, K, bf16, has_bias)
-    dx = _gemm(dy_op, _wt_op(w, bf16, ld), None, None, rows, ld, K, bf16)[0] if need_dx else None
+    dw, db = _wgrad(x_op, dy_op, rows, N, ld, K, bf16, has_bias, bufs)
+    dx = _gemm(dy_op, wt if wt is not None else _wt_op(w, bf16, ld), None, None, rows, ld, K, bf16)[0] if need_dx else None
     return dx, dw, db
 
 
@@ -331,25 +353,27 @@ class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b (+ res); x (rows, K) fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, bf16):
+    def forward(ctx, x, w, b, res, bf16, pack=None):
         rows, K = x.shape
         x = x.contiguous()
         xo = _cast(x, rows, K, K, True) if bf16 else x
-        out, _ = _gemm(xo, _w_op(w, bf16), None if b is None else b.detach(), None if res is None else res.contiguous(), rows, K, w.shape[0], bf16)
+        wf = pack[0] if pack is not None else _w_op(w, bf16)
+        out, _ = _gemm(xo, wf, None if b is None else b.detach(), None if res is None else res.contiguous(), rows, K, w.shape[0], bf16)
         ctx.save_for_backward(xo, w)
-        ctx.bf16, ctx.has_b, ctx.has_res = bf16, b is not None, res is not None
+        ctx.bf16, ctx.has_b, ctx.has_res, ctx.pack = bf16, b is not None, res is not None, pack
         return out
 
     @staticmethod
     def backward(ctx, dy):
         xo, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx, dw, db = _linear_bwd(xo, w, dy, xo.shape[0], ctx.bf16, ctx.has_b and ctx.needs_input_grad[2], need_dx=ctx.needs_input_grad[0])
-        return dx, dw, db, (dy if ctx.has_res else None), None
+        dx, dw, db = _linear_bwd(xo, w, dy, xo.shape[0], ctx.bf16, ctx.has_b and ctx.needs_input_grad[2], need_dx=ctx.needs_input_grad[0],
+                                 wt=None if ctx.pack is None else ctx.pack[1])
+        return dx, dw, db, (dy if ctx.has_res else None), None, None
 
 
-def linear(x, lin_w, lin_b, bf16, res=None):
-    return LinearFn.apply(x, lin_w, lin_b, res, bf16)
+def linear(x, lin_w, lin_b, bf16, res=None, pack=None):
+    return LinearFn.apply(x, lin_w, lin_b, res, bf16, pack)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -400,19 +424,19 @@ class AttnBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, ln_w, ln_b, w_in, b_in, w_out, b_out, rng, meta):
-        B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps = meta
+        B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps, pk_in, pk_out = meta
         E, R = H * hd, B * D
         h = h.contiguous()
         z, z_hi = _layernorm(h, None, ln_w, ln_b, None, eps, want_f32=not bf16, want_hi=bf16)
         z_op = (z_hi if bf16 else z).view(R, E)
-        qkv, _ = _gemm(z_op, _w_op(w_in, bf16), b_in.detach(), None, R, E, 3 * E, bf16)
+        qkv, _ = _gemm(z_op, pk_in[0], b_in.detach(), None, R, E, 3 * E, bf16)
         att, att_hi, stats = _attention_fwd(qkv, None, None, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16)
         att_op = att_hi if bf16 else att
         if p_drop > 0.0:
-            o, _ = _gemm(att_op, _w_op(w_out, bf16), b_out.detach(), None, R, E, E, bf16)
+            o, _ = _gemm(att_op, pk_out[0], b_out.detach(), None, R, E, E, bf16)
             out = _add(_dropout_(o, p_drop, rng, l_drop), h.view(R, E))
         else:
-            out, _ = _gemm(att_op, _w_op(w_out, bf16), b_out.detach(), h.view(R, E), R, E, E, bf16)
+            out, _ = _gemm(att_op, pk_out[0], b_out.detach(), h.view(R, E), R, E, E, bf16)
         ctx.save_for_backward(h, ln_w, ln_b, w_in, w_out, z_op, qkv, att, att_op, stats, rng)
         ctx.meta = meta
         return out.view(B, D, E)
@@ -420,15 +444,16 @@ class AttnBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         h, ln_w, ln_b, w_in, w_out, z_op, qkv, att, att_op, stats, rng = ctx.saved_tensors
-        B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps = ctx.meta
+        B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps, pk_in, pk_out = ctx.meta
         E, R = H * hd, B * D
         dout = dout.contiguous()
+        zw_out, zb_out, zw_in, zb_in, rep = _zeros(dout.device, (E, E), (E, 8), (3 * E, E), (3 * E, 8), (LN_REPLICAS, 2 * E))
         do = _dropout_(dout.clone(), p_drop, rng, l_drop) if p_drop > 0.0 else dout
-        datt, dw_out, db_out = _linear_bwd(att_op, w_out, do.view(R, E), R, bf16, True)
+        datt, dw_out, db_out = _linear_bwd(att_op, w_out, do.view(R, E), R, bf16, True, wt=pk_out[1], bufs=(zw_out, zb_out))
         (dqkv, _, _), hi = _attention_bwd(qkv, None, None, att, stats, datt, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16,
                                           want_f32=False)
-        dz, dw_in, db_in = _linear_bwd(z_op, w_in, dqkv, R, bf16, True, dy_hi=hi[0])
-        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone())
+        dz, dw_in, db_in = _linear_bwd(z_op, w_in, dqkv, R, bf16, True, dy_hi=hi[0], wt=pk_in[1], bufs=(zw_in, zb_in))
+        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone(), rep=rep)
         return dh, dg, dbeta, dw_in, db_in, dw_out, db_out, None, None
 
 
@@ -437,23 +462,23 @@ class MlpBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, ln_w, ln_b, w1, b1, w2, rng, meta):
-        B, D, E, p_drop, l1, l2, bf16, eps = meta
+        B, D, E, p_drop, l1, l2, bf16, eps, pk1, pk2 = meta
         R, M = B * D, w1.shape[0]
         h = h.contiguous()
         z, z_hi = _layernorm(h, None, ln_w, ln_b, None, eps, want_f32=not bf16, want_hi=bf16)
         z_op = (z_hi if bf16 else z).view(R, E)
         if p_drop > 0.0:
-            pre, _ = _gemm(z_op, _w_op(w1, bf16), b1.detach(), None, R, E, M, bf16)
+            pre, _ = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, bf16)
             u, u_hi = _act(pre, None, 1, p_drop, rng, l1, want_f32=not bf16, want_hi=bf16)
         else:
-            pre, u_hi = _gemm(z_op, _w_op(w1, bf16), b1.detach(), None, R, E, M, bf16, act=1, want_hi=bf16)     # relu(pre): same ReLU mask
+            pre, u_hi = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, bf16, act=1, want_hi=bf16)     # relu(pre): same ReLU mask
             u = pre
         u_op = u_hi if bf16 else u
         if p_drop > 0.0:
-            o, _ = _gemm(u_op, _w_op(w2, bf16), None, None, R, M, E, bf16)
+            o, _ = _gemm(u_op, pk2[0], None, None, R, M, E, bf16)
             out = _add(_dropout_(o, p_drop, rng, l2), h.view(R, E))
         else:
-            out, _ = _gemm(u_op, _w_op(w2, bf16), None, h.view(R, E), R, M, E, bf16)
+            out, _ = _gemm(u_op, pk2[0], None, h.view(R, E), R, M, E, bf16)
         ctx.save_for_backward(h, ln_w, ln_b, w1, w2, z_op, pre, u_op, rng)
         ctx.meta = meta
         return out.view(B, D, E)
@@ -461,14 +486,15 @@ class MlpBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         h, ln_w, ln_b, w1, w2, z_op, pre, u_op, rng = ctx.saved_tensors
-        B, D, E, p_drop, l1, l2, bf16, eps = ctx.meta
-        R = B * D
+        B, D, E, p_drop, l1, l2, bf16, eps, pk1, pk2 = ctx.meta
+        R, M = B * D, w1.shape[0]
         dout = dout.contiguous()
+        zw2, zw1, zb1, rep = _zeros(dout.device, (E, M), (M, E), (M, 8), (LN_REPLICAS, 2 * E))
         do = _dropout_(dout.clone(), p_drop, rng, l2) if p_drop > 0.0 else dout
-        du, dw2, _ = _linear_bwd(u_op, w2, do.view(R, E), R, bf16, False)
+        du, dw2, _ = _linear_bwd(u_op, w2, do.view(R, E), R, bf16, False, wt=pk2[1], bufs=(zw2, None))
         dpre, dpre_hi = _act(pre, du, 1, p_drop, rng if p_drop > 0 else None, l1, want_f32=not bf16, want_hi=bf16)
-        dz, dw1, db1 = _linear_bwd(z_op, w1, dpre, R, bf16, True, dy_hi=dpre_hi)
-        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone())
+        dz, dw1, db1 = _linear_bwd(z_op, w1, dpre, R, bf16, True, dy_hi=dpre_hi, wt=pk1[1], bufs=(zw1, zb1))
+        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone(), rep=rep)
         return dh, dg, dbeta, dw1, db1, dw2, None, None
 
 
@@ -581,6 +607,40 @@ class HollowTrainer:
         self.rng = torch.zeros(2, dtype=torch.int64, device=self.dev)
         self.rng[0] = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
         self.pe = None
+        self._pack_key, self._packs, self._pack_tab, self._pack_total = None, {}, None, 0
+
+    def _pack_weights(self, bump):
+        """ONE launch converts every matrix-core linear's weight into the forward operand [N][K] and the data-gradient
+        operand [K][N'] (transposed, N' = N rounded up to 16) in the mode's operand type; it also advances the dropout
+        stream.  The table is rebuilt when a parameter's storage moves."""
+        net, bf = self.net, self.precision == "bf16"
+        ws = [p for n, p in net.named_parameters()
+              if p.dim() == 2 and p.shape[1] % 16 == 0 and not n.startswith(("embedding", "temb_net", "input_embedding"))]
+        key = tuple(p.data_ptr() for p in ws)
+        if key != self._pack_key:
+            dt = torch.bfloat16 if bf else torch.float32
+            total = sum(2 * p.shape[1] * (-(-p.shape[0] // 16) * 16) for p in ws)
+            arena = torch.zeros(total, dtype=dt, device=self.dev)
+            tab = (unet_train._PackEntry * len(ws))()
+            o, first, packs = 0, 0, {}
+            for i, p in enumerate(ws):
+                N, K = p.shape
+                ld = -(-N // 16) * 16
+                fwd, dg = arena[o:o + N * K].view(N, K), arena[o + ld * K:o + 2 * ld * K].view(K, ld)
+                o += 2 * ld * K
+                t = tab[i]
+                t.w, t.fwd, t.dgrad = p.data_ptr(), fwd.data_ptr(), dg.data_ptr()
+                t.N, t.Cin_tot, t.c_off, t.C, t.ntap, t.Ktot, t.koff, t.flip, t.ldd, t.first = N, K, 0, K, 1, K, 0, 0, ld, first
+                first += N * K
+                packs[id(p)] = (fwd, dg)
+            self._pack_key, self._packs, self._pack_total, self._arena = key, packs, first, arena
+            self._pack_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.dev)
+            self._pack_n = len(ws)
+        _ck(lib().ctdd_unet_pack_weights(self._pack_tab.data_ptr(), self._pack_n, self._pack_total, 0 if bf else 1,
+                                         self.rng.data_ptr() if bump else None, _st()), "ctdd_unet_pack_weights")
+
+    def pk(self, w):
+        return self._packs[id(w)]
 
     def __call__(self, x, times):
         net = self.net
@@ -592,9 +652,8 @@ class HollowTrainer:
         training = bool(self.model.training)
         p_drop = float(m.dropout_rate) if training else 0.0
         p_att = float(m.attention_dropout_rate) if training else 0.0
-        if training:
-            self.rng[1] += 1                                  # one dropout stream per training forward
-        rng = self.rng
+        self._pack_weights(bump=training)                     # (+ one dropout stream per training forward)
+        rng, pk = self.rng, self.pk
         layer = [0]
 
         def nxt():
@@ -615,11 +674,15 @@ class HollowTrainer:
                 sa, ff = blk.self_attention_block, blk.feed_forward_block
                 mha = sa.self_attention
                 h = AttnBlockFn.apply(h, sa.norm.weight, sa.norm.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
-                                      mha.out_proj.bias, rng, (B, D, H, hd, mode, p_att, p_drop, nxt(), nxt(), bf, sa.norm.eps))
+                                      mha.out_proj.bias, rng,
+                                      (B, D, H, hd, mode, p_att, p_drop, nxt(), nxt(), bf, sa.norm.eps, pk(mha.in_proj_weight), pk(mha.out_proj.weight)))
                 h = MlpBlockFn.apply(h, ff.norm.weight, ff.norm.bias, ff.mlp.fc1.weight, ff.mlp.fc1.bias, ff.mlp.fc2.weight, rng,
-                                     (B, D, E, p_drop, nxt(), nxt(), bf, ff.norm.eps))
+                                     (B, D, E, p_drop, nxt(), nxt(), bf, ff.norm.eps, pk(ff.mlp.fc1.weight), pk(ff.mlp.fc2.weight)))
             streams.append(h)
         l2r, r2l = streams
+        def dense(x_, w_, b_, use_bf, res=None):                # packed operands when the pack's type is the layer's
+            return linear(x_, w_, b_, use_bf, res, pk(w_) if use_bf == bf else None)
+
         # ---- attention readout (prenorm): cross attention over [temb | ln1(l2r) | ln2(r2l)] + (l2r + r2l)
         ro = net.readout_module
         ca = ro.cross_attention
@@ -629,22 +692,22 @@ class HollowTrainer:
         allk = torch.cat([temb.unsqueeze(1), a1, a2], dim=1).reshape(B * Tk, E)
         qin = AddFn.apply(a1, a2).view(R, E)
         raw = AddFn.apply(l2r, r2l).view(R, E)
-        qb = linear(qin, ca.dense_query.weight, None, bf)
-        kb = linear(allk, ca.dense_key.weight, ca.dense_key.bias, bf)
-        vb = linear(allk, ca.dense_val.weight, ca.dense_val.bias, bf)
+        qb = dense(qin, ca.dense_query.weight, None, bf)
+        kb = dense(allk, ca.dense_key.weight, ca.dense_key.bias, bf)
+        vb = dense(allk, ca.dense_val.weight, ca.dense_val.bias, bf)
         ctxv = AttentionFn.apply(qb, kb, vb, B, D, Tk, H, hd, 2, 0.0, None, nxt(), bf)
-        xr = linear(ctxv, ca.out_linear.weight, ca.out_linear.bias, bf, res=raw)
+        xr = dense(ctxv, ca.out_linear.weight, ca.out_linear.bias, bf, res=raw)
         # ---- FiLM residual readout
         rr = ro.model
         E2 = 2 * E
         lin = [l_ for l_ in rr.mlp.layers if isinstance(l_, torch.nn.Linear)]
-        tm = linear(ActFn.apply(linear(temb, lin[0].weight, lin[0].bias, False), 2, 0.0, None, 0), lin[1].weight, lin[1].bias, False)
-        hh = linear(xr, rr.input_layer.weight, rr.input_layer.bias, bf)
+        tm = dense(ActFn.apply(dense(temb, lin[0].weight, lin[0].bias, False), 2, 0.0, None, 0), lin[1].weight, lin[1].bias, False)
+        hh = dense(xr, rr.input_layer.weight, rr.input_layer.bias, bf)
         for i in range(rr.n_res):
             mlp_i, ln_i = rr.resid_layers[2 * i], rr.resid_layers[2 * i + 1]
             li = [l_ for l_ in mlp_i.layers if isinstance(l_, torch.nn.Linear)]
-            r_ = linear(ActFn.apply(linear(hh, li[0].weight, li[0].bias, bf), 2, 0.0, None, 0), li[1].weight, li[1].bias, bf)
-            fl = linear(tm, rr.film_layer[i].weight, rr.film_layer[i].bias, False)
+            r_ = dense(ActFn.apply(dense(hh, li[0].weight, li[0].bias, bf), 2, 0.0, None, 0), li[1].weight, li[1].bias, bf)
+            fl = dense(tm, rr.film_layer[i].weight, rr.film_layer[i].bias, False)
             hh = LayerNormFn.apply(hh.view(B, D, E2), r_.view(B, D, E2), ln_i.weight, ln_i.bias, fl, ln_i.eps).view(R, E2)
-        logits = linear(hh, rr.logits_layer.weight, rr.logits_layer.bias, bf)
+        logits = dense(hh, rr.logits_layer.weight, rr.logits_layer.bias, bf)
         return logits.view(B, D, rr.out_dim)

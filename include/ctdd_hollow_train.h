@@ -21,6 +21,8 @@ typedef struct {
   const float* x; const float* y; int64_t x_bs, y_bs; const float* gamma; const float* beta; float eps;
   const float* film; int film_stride; const float* dout; int64_t dout_bs; int B, T, E, rpw;
   float* dx; int64_t dx_bs; int acc_dx; float* dy; int64_t dy_bs; int acc_dy; float* dgamma; float* dbeta; float* dfilm;
+  int nrep, rep_stride;   /* nrep > 1: workgroup w accumulates into dgamma / dbeta + (w % nrep) * rep_stride; the caller sums the replicas
+                             (thousands of workgroups on the same 2E addresses serialise in L2) */
 } ctdd_hollow_ln_bwd_args;
 int ctdd_hollow_layernorm_bwd(const void* ln_bwd_args, void* stream);
 
