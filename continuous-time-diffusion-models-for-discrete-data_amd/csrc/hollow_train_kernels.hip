@@ -382,22 +382,40 @@ __device__ inline bool chunk_full(int mode, int Tq, int Tk, int j0, int q0) {   
 }
 constexpr int RLD16 = 8, TLD = 40;                  // row-major rows: HD + 8 bf16; transposed rows: 32 + 8
 
-// stage 32 rows [row][HD] of an fp32 matrix as bf16: row-major into R (when given) and transposed [dim][row] into T (when given)
+// Staging of a chunk of 32 rows of TWO fp32 matrices [row][HD] as bf16, split in a fetch (global -> registers, issued a chunk
+// ahead so that the loads fly under the previous chunk's products) and a store (registers -> LDS: row-major R and / or
+// transposed T [dim][row]).  256 threads: item = (matrix, row, four dims); HD / 16 items per thread.
 template <int HD>
-__device__ inline void stage32(const float* base, int64_t rs, int r0, int rmax, float scale, unsigned short* R, unsigned short* T) {
-  constexpr int RLD = HD + RLD16;
-  if (threadIdx.x < 32 * HD / 4) {
-    const int rr = threadIdx.x / (HD / 4), c4 = (threadIdx.x % (HD / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 + rr < rmax) v = *(const float4*)(base + (size_t)(r0 + rr) * rs + c4);
-    const unsigned p01 = ht_pack2(v.x * scale, v.y * scale), p23 = ht_pack2(v.z * scale, v.w * scale);
-    if (R) *(uint2*)(R + rr * RLD + c4) = make_uint2(p01, p23);
-    if (T) {
-      T[(c4 + 0) * TLD + rr] = (unsigned short)(p01 & 0xFFFFu); T[(c4 + 1) * TLD + rr] = (unsigned short)(p01 >> 16);
-      T[(c4 + 2) * TLD + rr] = (unsigned short)(p23 & 0xFFFFu); T[(c4 + 3) * TLD + rr] = (unsigned short)(p23 >> 16);
+struct Stage2 {
+  static constexpr int NU = HD / 16, ITEMS = 32 * HD / 4;
+  float4 v[NU];
+  __device__ inline void fetch(const float* m0, int64_t rs0, const float* m1, int64_t rs1, int r0, int rmax) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = threadIdx.x + 256 * u, mat = idx / ITEMS, r = idx % ITEMS;
+      const int rr = r / (HD / 4), c4 = (r % (HD / 4)) * 4;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + rr < rmax) v[u] = *(const float4*)((mat ? m1 : m0) + (size_t)(r0 + rr) * (mat ? rs1 : rs0) + c4);
     }
   }
-}
+  __device__ inline void store(float scale0, unsigned short* R0, unsigned short* T0, unsigned short* R1, unsigned short* T1) const {
+    constexpr int RLD = HD + RLD16;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = threadIdx.x + 256 * u, mat = idx / ITEMS, r = idx % ITEMS;
+      const int rr = r / (HD / 4), c4 = (r % (HD / 4)) * 4;
+      const float sc = mat ? 1.0f : scale0;
+      const unsigned p01 = ht_pack2(v[u].x * sc, v[u].y * sc), p23 = ht_pack2(v[u].z * sc, v[u].w * sc);
+      unsigned short* R = mat ? R1 : R0;
+      unsigned short* T = mat ? T1 : T0;
+      if (R) *(uint2*)(R + rr * RLD + c4) = make_uint2(p01, p23);
+      if (T) {
+        T[(c4 + 0) * TLD + rr] = (unsigned short)(p01 & 0xFFFFu); T[(c4 + 1) * TLD + rr] = (unsigned short)(p01 >> 16);
+        T[(c4 + 2) * TLD + rr] = (unsigned short)(p23 & 0xFFFFu); T[(c4 + 3) * TLD + rr] = (unsigned short)(p23 >> 16);
+      }
+    }
+  }
+};
 // A operand of a product contracting over the 32 staged rows, from a transposed tile: lane = dim column, rows in register order
 __device__ inline bf16x8t tfrag(const unsigned short* T, int col, int kh, int s_) {
   const unsigned short* p = T + col * TLD + 16 * s_ + 4 * kh;
@@ -444,12 +462,20 @@ __global__ __launch_bounds__(256) void k_hollow_attn_q_mfma(const AttnTrainArgs 
   const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tq) - 1, mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;
   const float* kb = a.k + (size_t)b * a.k_bs + h * HD;
   const float* vb = a.v + (size_t)b * a.v_bs + h * HD;
-  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
-    if (!chunk_any(a.mode, a.Tq, a.Tk, j0, wlo, whi)) continue;                 // (uniform over the workgroup)
+  Stage2<HD> stg;
+  auto next_visible = [&](int jc) {                                             // (uniform over the workgroup)
+    while (jc < a.Tk && !chunk_any(a.mode, a.Tq, a.Tk, jc, wlo, whi)) jc += 32;
+    return jc;
+  };
+  int jnext = next_visible(0);
+  if (jnext < a.Tk) stg.fetch(kb, a.k_rs, vb, a.v_rs, jnext, a.Tk);
+  while (jnext < a.Tk) {
+    const int j0 = jnext;
     __syncthreads();
-    stage32<HD>(kb, a.k_rs, j0, a.Tk, 1.0f, Kr, BWD ? Tt : nullptr);
-    stage32<HD>(vb, a.v_rs, j0, a.Tk, 1.0f, BWD ? Vr : nullptr, BWD ? nullptr : Tt);
+    stg.store(1.0f, Kr, BWD ? Tt : nullptr, BWD ? Vr : nullptr, BWD ? nullptr : Tt);
     __syncthreads();
+    jnext = next_visible(j0 + 32);
+    if (jnext < a.Tk) stg.fetch(kb, a.k_rs, vb, a.v_rs, jnext, a.Tk);
     if (!chunk_any(a.mode, a.Tq, a.Tk, j0, mylo, myhi)) continue;               // (wave-uniform; no barrier below)
     f32x16t sacc, pacc;
 #pragma unroll
@@ -565,17 +591,31 @@ __global__ __launch_bounds__(256) void k_hollow_attn_kv_mfma(const AttnTrainArgs
   const float* qb = a.q + (size_t)b * a.q_bs + h * HD;
   const float* db = a.d_out + (size_t)b * a.Tq * a.out_rs + h * HD;
   const float* sb = a.stats + ((size_t)b * a.H + h) * a.Tq * 4;
-  for (int i0 = 0; i0 < a.Tq; i0 += 32) {
-    if (!q_any(i0, wlo, whi)) continue;                                         // (uniform over the workgroup)
-    __syncthreads();
-    stage32<HD>(qb, a.q_rs, i0, a.Tq, a.scale, Qr, Qt);
-    stage32<HD>(db, a.out_rs, i0, a.Tq, 1.0f, Dr, Dt);
+  Stage2<HD> stg;
+  float pm = 0.0f, pl = 0.0f, pd = 0.0f;                                         // the chunk's row statistics, fetched ahead (threads 0..31)
+  auto next_visible = [&](int ic) {                                             // (uniform over the workgroup)
+    while (ic < a.Tq && !q_any(ic, wlo, whi)) ic += 32;
+    return ic;
+  };
+  auto fetch = [&](int ic) {
+    stg.fetch(qb, a.q_rs, db, a.out_rs, ic, a.Tq);
     if (threadIdx.x < 32) {
-      const int i = i0 + threadIdx.x;
+      const int i = ic + threadIdx.x;
       const bool ok = i < a.Tq;
-      Sm[threadIdx.x] = ok ? sb[(size_t)i * 4] : 0.0f;
-      Sl[threadIdx.x] = ok ? 1.0f / sb[(size_t)i * 4 + 1] : 0.0f;
-      Sd[threadIdx.x] = ok ? sb[(size_t)i * 4 + 2] : 0.0f;
+      pm = ok ? sb[(size_t)i * 4] : 0.0f;
+      pl = ok ? sb[(size_t)i * 4 + 1] : 1.0f;
+      pd = ok ? sb[(size_t)i * 4 + 2] : 0.0f;
+    }
+  };
+  // (no fetch-ahead here: the two accumulators + fragments already hold this kernel at 3 waves per SIMD, and the extra
+  //  registers of a chunk in flight cost more than the exposed load latency -- measured 158 us vs 183 us per call)
+  for (int i0 = next_visible(0); i0 < a.Tq; i0 = next_visible(i0 + 32)) {
+    fetch(i0);
+    __syncthreads();
+    stg.store(a.scale, Qr, Qt, Dr, Dt);
+    if (threadIdx.x < 32) {
+      const bool ok = i0 + (int)threadIdx.x < a.Tq;
+      Sm[threadIdx.x] = pm; Sl[threadIdx.x] = ok ? 1.0f / pl : 0.0f; Sd[threadIdx.x] = pd;
     }
     __syncthreads();
     if (!q_any(i0, mylo, myhi)) continue;                                       // (wave-uniform; no barrier below)

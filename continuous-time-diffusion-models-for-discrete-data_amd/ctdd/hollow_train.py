@@ -113,7 +113,7 @@ def _gemm(x, w, bias, res, rows, K, N, bf16, act=0, want_hi=False, want_f32=True
         _ck(l.ctdd_unet_conv(C.byref(a), bk, 1, 0, _st()), "ctdd_unet_conv")
     else:
         bk = 32 if K % 32 == 0 else 16
-        bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
+        bnt = 1 if (bk == 16 or rows <= 512) else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)   # few rows (per-sample layers): narrow tiles, more workgroups
         _ck(l.ctdd_unet_conv(C.byref(a), bk, bnt, 1, _st()), "ctdd_unet_conv")
     return out, out_hi
 
