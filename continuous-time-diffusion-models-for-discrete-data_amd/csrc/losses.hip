@@ -259,7 +259,11 @@ __global__ __launch_bounds__(256) void k_elbo_atab(const ElboArgs a) {
   }
 }
 
-// forward rows.  grid (ceil(D/LRB), B)
+// forward rows.  grid (ceil(D/LRB), B).  PHASE 0: everything, the S x S contraction as fp32 FMA chains (any S <= 256);
+// S % 32 == 0 (MNIST / CIFAR: S = 256) splits it around the matrix-core GEMM k_bgemm_f32:  PHASE 1 writes the left operand
+// rvec = p / (q[., x] + eps) (into the grad buffer, free until backward) and the reg / nll row sums,  PHASE 2 reads u = rvec @ q
+// back and forms the outer / norm row sums.
+template <int PHASE>
 __global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
   __shared__ float rvec[LRB][256];
   __shared__ float red[4 * LRB];
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
   int x[LRB], x0[LRB];
   bool ok[LRB];
   float l[LRB], mx[LRB], tmp[LRB], p[LRB];
+  auto row_of = [&](int r) { return (size_t)b * D + d0 + r; };
 #pragma unroll
   for (int r = 0; r < LRB; ++r) {
     ok[r] = d0 + r < D;
@@ -291,15 +296,33 @@ __global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
     const float L = mx[r] + logf(zs[r]);
     p[r] = act ? expf(l[r] - L) : 0.0f;
     const float den = act ? qT[(size_t)x[r] * S + t] + a.eps : 1.0f;
-    rvec[r][t] = p[r] / den;
+    if (PHASE == 1) { if (act && ok[r]) a.grad[row_of(r) * S + t] = p[r] / den; }
+    else rvec[r][t] = p[r] / den;
     regp[r] = act ? p[r] * a.Atab[((size_t)b * S + x[r]) * S + t] : 0.0f;
     nllp[r] = (act && t == x0[r]) ? -(l[r] - L) : 0.0f;
+  }
+  if (PHASE == 1) {
+    float o3[LRB], o4[LRB];
+    block_sum8(regp, red, o3);
+    block_sum8(nllp, red, o4);
+    if (t < LRB && d0 + t < D) {
+      double* dst = a.rows + ((size_t)b * D + d0 + t) * 4;
+      float v3 = 0, v4 = 0;
+#pragma unroll
+      for (int r = 0; r < LRB; ++r)
+        if (r == t) { v3 = o3[r]; v4 = o4[r]; }
+      dst[2] = v3; dst[3] = v4;
+    }
+    return;
   }
   __syncthreads();
   float acc[LRB];
 #pragma unroll
   for (int r = 0; r < LRB; ++r) acc[r] = 0.0f;
-  if (act)
+  if (PHASE == 2) {
+#pragma unroll
+    for (int r = 0; r < LRB; ++r) acc[r] = (act && ok[r]) ? a.u[row_of(r) * S + t] : 0.0f;
+  } else if (act)
     for (int s0 = 0; s0 < S; ++s0) {
       const float qv = q[(size_t)s0 * S + t];
 #pragma unroll
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
     outp[r] = 0.0f; normp[r] = 0.0f;
     if (act) {
       const size_t row = (size_t)b * D + d0 + r;
-      if (ok[r]) a.u[row * S + t] = acc[r];
+      if (PHASE == 0 && ok[r]) a.u[row * S + t] = acc[r];
       const float orate = t == x[r] ? 0.0f : R[(size_t)t * S + x[r]];
       const float qx0 = q[(size_t)x0[r] * S + t];
       const float qx0xt = q[(size_t)x0[r] * S + x[r]] + a.eps;
@@ -324,28 +347,126 @@ __global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
   float o1[LRB], o2[LRB], o3[LRB], o4[LRB];
   block_sum8(outp, red, o1);
   block_sum8(normp, red, o2);
-  block_sum8(regp, red, o3);
-  block_sum8(nllp, red, o4);
+  if (PHASE == 0) { block_sum8(regp, red, o3); block_sum8(nllp, red, o4); }
   if (t < LRB && d0 + t < D) {
     double* dst = a.rows + ((size_t)b * D + d0 + t) * 4;
     float v1 = 0, v2 = 0, v3 = 0, v4 = 0;
 #pragma unroll
     for (int r = 0; r < LRB; ++r)
-      if (r == t) { v1 = o1[r]; v2 = o2[r]; v3 = o3[r]; v4 = o4[r]; }
-    dst[0] = v1; dst[1] = v2; dst[2] = v3; dst[3] = v4;
+      if (r == t) { v1 = o1[r]; v2 = o2[r]; if (PHASE == 0) { v3 = o3[r]; v4 = o4[r]; } }
+    dst[0] = v1; dst[1] = v2;
+    if (PHASE == 0) { dst[2] = v3; dst[3] = v4; }
   }
 }
 
+
+// ---- C_b = A_b W_b^T on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32): A (B, M, K), W (B, N, K), C (B, M, N)
+// with K = N = 32 NT (S = 256: NT = 8).  Workgroup = 128 rows x all N of one sample, a wave = 32 rows x N (NT accumulator
+// tiles); K in chunks of 16 through LDS (rows padded to 20 floats: the 16-byte fragment reads of 16 lanes cover all 64
+// banks), next chunk's global loads in registers behind the current chunk's 16 NT matrix instructions per wave.  A lane half
+// g contracts k = 8 g .. 8 g + 7 of the chunk: each 16-byte read feeds four instructions.
+constexpr int GK = 16, GLD = GK + 4;
+template <int NT>
+__global__ __launch_bounds__(256) void k_bgemm_f32(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ Cm, int M) {
+  constexpr int N = 32 * NT, K = N, WV = (NT + 1) / 2;              // WV: float4 of W per thread and chunk (N * 16 / 4 / 256, rounded up)
+  __shared__ __attribute__((aligned(16))) float As[2][128 * GLD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][N * GLD];
+  using f32x16l = __attribute__((ext_vector_type(16))) float;
+  const int b = blockIdx.y, m0 = blockIdx.x * 128, t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, g = lane >> 5;
+  const float* Ab = A + (size_t)b * M * K;
+  const float* Wb = W + (size_t)b * N * K;
+  float4 pa[2], pw[WV];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = t + 256 * u, row = idx >> 2, c4 = (idx & 3) * 4;
+      pa[u] = m0 + row < M ? *(const float4*)(Ab + (size_t)(m0 + row) * K + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < WV; ++u) {
+      const int idx = t + 256 * u, n = idx >> 2, c4 = (idx & 3) * 4;
+      pw[u] = n < N ? *(const float4*)(Wb + (size_t)n * K + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = t + 256 * u, row = idx >> 2, c4 = (idx & 3) * 4;
+      *(float4*)(&As[buf][row * GLD + c4]) = pa[u];
+    }
+#pragma unroll
+    for (int u = 0; u < WV; ++u) {
+      const int idx = t + 256 * u, n = idx >> 2, c4 = (idx & 3) * 4;
+      if (n < N) *(float4*)(&Ws[buf][n * GLD + c4]) = pw[u];
+    }
+  };
+  f32x16l acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < K / GK; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < K / GK) fetch((c + 1) * GK);
+    const float* Aw = &As[buf][(wave * 32 + li) * GLD + 8 * g];
+    const float* Ww = &Ws[buf][li * GLD + 8 * g];
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) {
+      const float4 av = *(const float4*)(Aw + 4 * s4);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const float4 bv = *(const float4*)(Ww + (size_t)i * 32 * GLD + 4 * s4);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[i], 0, 0, 0);
+      }
+    }
+    if (c + 1 < K / GK) stash(buf ^ 1);          // (the other buffer: its readers passed the barrier of the previous chunk)
+    __syncthreads();
+  }
+  // accumulator tile i: column 32 i + li, rows (r & 3) + 8 (r >> 2) + 4 g of the wave's 32
+  float* Cb = Cm + (size_t)b * M * N;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+      if (row < M) Cb[(size_t)row * N + 32 * i + li] = acc[i][r];
+    }
+}
+
+// per-sample sums of the four row quantities: one workgroup per sample -> sums (B, 4) fp64
+__global__ __launch_bounds__(256) void k_elbo_sample_sums(const ElboArgs a, double* __restrict__ sums) {
+  __shared__ double red[4][256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int d = t; d < a.D; d += 256) {
+    const double* r = a.rows + ((size_t)b * a.D + d) * 4;
+    s[0] += r[0]; s[1] += r[1]; s[2] += r[2]; s[3] += r[3];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][t] = s[k];
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (t < o) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][t] += red[k][t + o];
+    }
+    __syncthreads();
+  }
+  if (t < 4) sums[(size_t)b * 4 + t] = red[t][0];
+}
+
 // per-sample sums -> c_b and the scalar loss.  one workgroup.
-__global__ __launch_bounds__(256) void k_elbo_reduce(const ElboArgs a) {
+__global__ __launch_bounds__(256) void k_elbo_reduce(const ElboArgs a, const double* __restrict__ sums) {
   __shared__ double acc[256];
   double tot = 0.0;
   for (int b = threadIdx.x; b < a.B; b += 256) {
-    double so = 0.0, sn = 0.0, sr = 0.0, sl = 0.0;
-    for (int d = 0; d < a.D; ++d) {
-      const double* r = a.rows + ((size_t)b * a.D + d) * 4;
-      so += r[0]; sn += r[1]; sr += r[2]; sl += r[3];
-    }
+    const double so = sums[(size_t)b * 4], sn = sums[(size_t)b * 4 + 1], sr = sums[(size_t)b * 4 + 2], sl = sums[(size_t)b * 4 + 3];
     a.cb[b] = (float)(-(double)a.elbo_scale / ((double)a.B * sn));
     tot += (double)a.elbo_scale * ((-so / sn) + sr) / (double)a.B + (double)a.nll_scale * sl;
   }
@@ -358,7 +479,9 @@ __global__ __launch_bounds__(256) void k_elbo_reduce(const ElboArgs a) {
   if (threadIdx.x == 0) a.out_loss[0] = (float)acc[0];
 }
 
-// backward rows.  grid (ceil(D/LRB), B)
+// backward rows.  grid (ceil(D/LRB), B).  PHASE 0: everything (fp32 FMA contraction);  PHASE 1: G rows -> the grad buffer (the
+// matrix-core GEMM then writes dr = G @ q^T over u);  PHASE 2: dr -> d/dlogits.
+template <int PHASE>
 __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
   __shared__ float gvec[LRB][256];
   __shared__ float red[4 * LRB];
@@ -381,14 +504,16 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
     tmp[r] = l[r];
     // G[s] = c_b Wt[s] / (u[s] + eps)
     float G = 0.0f;
-    if (act) {
+    if (act && PHASE != 2) {
       const float orate = t == x[r] ? 0.0f : R[(size_t)t * S + x[r]];
       const float qx0 = q[(size_t)x0[r] * S + t];
       const float qx0xt = q[(size_t)x0[r] * S + x[r]] + a.eps;
       G = cb * orate * (qx0 / qx0xt) / (a.u[row * S + t] + a.eps);
     }
-    gvec[r][t] = G;
+    if (PHASE == 1) { if (act && ok[r]) a.grad[row * S + t] = G; }
+    else if (PHASE == 0) gvec[r][t] = G;
   }
+  if (PHASE == 1) return;
   block_max8(tmp, red, mx);                          // (contains the barrier that publishes gvec)
 #pragma unroll
   for (int r = 0; r < LRB; ++r) tmp[r] = act ? expf(l[r] - mx[r]) : 0.0f;
@@ -397,7 +522,10 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
   float acc[LRB];
 #pragma unroll
   for (int r = 0; r < LRB; ++r) { acc[r] = 0.0f; p[r] = act ? expf(l[r] - (mx[r] + logf(zs[r]))) : 0.0f; }
-  if (act)
+  if (PHASE == 2) {
+#pragma unroll
+    for (int r = 0; r < LRB; ++r) acc[r] = (act && ok[r]) ? a.u[((size_t)b * D + d0 + r) * S + t] : 0.0f;
+  } else if (act)
     for (int s = 0; s < S; ++s) {                    // dr[s0 = t] = sum_s G[s] q[s0, s] = sum_s G[s] qT[s, s0]
       const float qv = qT[(size_t)s * S + t];
 #pragma unroll
@@ -421,9 +549,9 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
 }  // namespace ctdd
 
 extern "C" int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S) {
-  // Atab (B,S,S) f32 | u (B,D,S) f32 | rows (B*D,4) f64 | base_sum (B) f32 | cb (B) f32   (each 256-B aligned)
+  // Atab (B,S,S) f32 | u (B,D,S) f32 | rows (B*D,4) f64 | base_sum (B) f32 | cb (B) f32 | sums (B,4) f64   (each 256-B aligned)
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al((int64_t)B * S * S * 4) + al((int64_t)B * D * S * 4) + al((int64_t)B * D * 32) + 2 * al((int64_t)B * 4);
+  return al((int64_t)B * S * S * 4) + al((int64_t)B * D * S * 4) + al((int64_t)B * D * 32) + 2 * al((int64_t)B * 4) + al((int64_t)B * 32);
 }
 
 extern "C" int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
@@ -440,16 +568,49 @@ extern "C" int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const in
   a.u = (float*)sp; sp += al((int64_t)B * D * S * 4);
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
   a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
-  a.cb = (float*)sp;
+  a.cb = (float*)sp; sp += al((int64_t)B * 4);
+  double* sums = (double*)sp;
   a.grad = grad_logits; a.out_loss = out_loss; a.ll_in = 0;
   hipStream_t st = (hipStream_t)stream;
+  const dim3 rg((D + LRB - 1) / LRB, B), gg((D + 127) / 128, B);
+  const bool mfma = S % 32 == 0;                     // the S x S contractions on the exact-fp32 matrix instruction
   hipLaunchKernelGGL(k_elbo_atab, dim3((S + LRB - 1) / LRB, B), dim3(256), 0, st, a);
   if (int rc = finish_launch("k_elbo_atab")) return rc;
-  hipLaunchKernelGGL(k_elbo_fwd, dim3((D + LRB - 1) / LRB, B), dim3(256), 0, st, a);
-  if (int rc = finish_launch("k_elbo_fwd")) return rc;
-  hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a);
+  auto gemm = [&](const float* Am, const float* Wm, float* Cm) {
+    switch (S / 32) {
+      case 1: hipLaunchKernelGGL(k_bgemm_f32<1>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 2: hipLaunchKernelGGL(k_bgemm_f32<2>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 3: hipLaunchKernelGGL(k_bgemm_f32<3>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 4: hipLaunchKernelGGL(k_bgemm_f32<4>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 5: hipLaunchKernelGGL(k_bgemm_f32<5>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 6: hipLaunchKernelGGL(k_bgemm_f32<6>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 7: hipLaunchKernelGGL(k_bgemm_f32<7>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      default: hipLaunchKernelGGL(k_bgemm_f32<8>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+    }
+    return finish_launch("k_bgemm_f32");
+  };
+  if (mfma) {
+    hipLaunchKernelGGL(k_elbo_fwd<1>, rg, dim3(256), 0, st, a);                 // rvec -> grad buffer; reg / nll row sums
+    if (int rc = finish_launch("k_elbo_fwd<1>")) return rc;
+    if (int rc = gemm(a.grad, a.qT, a.u)) return rc;                            // u[row][s] = sum_s0 rvec[row][s0] qT[s][s0]
+    hipLaunchKernelGGL(k_elbo_fwd<2>, rg, dim3(256), 0, st, a);
+    if (int rc = finish_launch("k_elbo_fwd<2>")) return rc;
+  } else {
+    hipLaunchKernelGGL(k_elbo_fwd<0>, rg, dim3(256), 0, st, a);
+    if (int rc = finish_launch("k_elbo_fwd")) return rc;
+  }
+  hipLaunchKernelGGL(k_elbo_sample_sums, dim3(B), dim3(256), 0, st, a, sums);
+  if (int rc = finish_launch("k_elbo_sample_sums")) return rc;
+  hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a, (const double*)sums);
   if (int rc = finish_launch("k_elbo_reduce")) return rc;
-  hipLaunchKernelGGL(k_elbo_bwd, dim3((D + LRB - 1) / LRB, B), dim3(256), 0, st, a);
+  if (mfma) {
+    hipLaunchKernelGGL(k_elbo_bwd<1>, rg, dim3(256), 0, st, a);                 // G -> grad buffer
+    if (int rc = finish_launch("k_elbo_bwd<1>")) return rc;
+    if (int rc = gemm(a.grad, a.q, a.u)) return rc;                             // dr[row][s0] = sum_s G[row][s] q[s0][s]   (over u)
+    hipLaunchKernelGGL(k_elbo_bwd<2>, rg, dim3(256), 0, st, a);
+    return finish_launch("k_elbo_bwd<2>");
+  }
+  hipLaunchKernelGGL(k_elbo_bwd<0>, rg, dim3(256), 0, st, a);
   return finish_launch("k_elbo_bwd");
 }
 
@@ -572,7 +733,8 @@ static int score_elbo_impl(const float* logits, const int32_t* x0, const int32_t
   a.u = (float*)sp; sp += al((int64_t)B * D * S * 4);
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
   a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
-  a.cb = (float*)sp;
+  a.cb = (float*)sp; sp += al((int64_t)B * 4);
+  double* sums = (double*)sp;
   a.grad = grad_logits; a.out_loss = out_loss; a.ll_in = ll_in;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * D;
@@ -580,7 +742,9 @@ static int score_elbo_impl(const float* logits, const int32_t* x0, const int32_t
   if (int rc = finish_launch("k_elbo_atab")) return rc;
   hipLaunchKernelGGL(k_selbo_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, reg_x);
   if (int rc = finish_launch("k_selbo_fwd")) return rc;
-  hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_elbo_sample_sums, dim3(B), dim3(256), 0, st, a, sums);
+  if (int rc = finish_launch("k_elbo_sample_sums")) return rc;
+  hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a, (const double*)sums);
   if (int rc = finish_launch("k_elbo_reduce")) return rc;
   hipLaunchKernelGGL(k_selbo_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, reg_x);
   return finish_launch("k_selbo_bwd");
