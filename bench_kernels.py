@@ -28,13 +28,33 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
 def timeit(fn, reps, warm=3):
+    """Seconds per launch: `reps` launches captured into ONE HIP graph (back-to-back on the device: a ctypes launch costs the
+    host ~13 us, more than the small-S kernels run), HIP events around its replay; eager launches if capture fails."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    graph = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        graph = g
+    except Exception:                                   # (a kernel that allocates outside the graph pool, a host sync ...)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(reps):
+            fn()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / reps
@@ -44,6 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="one batch size per shape")
     ap.add_argument("--out", default=None, help="also append the lines to this file")
+    ap.add_argument("--shapes", default=None, help="comma-separated subset of mnist,cifar10,maze,synthetic")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_kernels.py needs a GPU: libctdd has no CPU path")
@@ -73,6 +94,8 @@ def main():
     ]
     h, eps, seed = 1e-3, 1e-9, 42
     for name, D, S, kind, params, batches in shapes:
+        if a.shapes and name not in a.shapes.split(","):
+            continue
         pr = DeviceForwardProcess(kind, S, dev, **params)
         if a.quick:
             batches = batches[1:2]

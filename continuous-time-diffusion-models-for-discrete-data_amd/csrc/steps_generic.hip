@@ -477,7 +477,294 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
   }  // rows of this wave
 }
 
+
+// ============================================================================ S <= 8 (maze S = 3, synthetic S = 2): a row per lane, FOUR rows per thread
+// The fused sampler steps (one q_{t|0} / rate table for the whole launch) at small S move 4 S + 8 bytes per row: the generic
+// kernel above spends ~1000 instructions on each (run-time S / mode / group-size tests, per-row table addressing, 4-byte loads).
+// Here S and the mode are compile-time, a thread owns four CONSECUTIVE rows (their 4 S logits are S aligned 16-byte loads, the
+// states one int4 each way), both tables sit in LDS, and every row loop is unrolled straight-line code in the operation order
+// of k_rows with G = 1 (sequential sums in s order -- for S <= 4 bit-identical to it, for 5 <= S <= 8 the oracle's own order
+// where k_rows uses a lane tree).  Same Philox streams, same draw rules (draw.hpp).
+template <int S, int MODE>
+__global__ __launch_bounds__(256) void k_rows_small(const StepArgs a) {
+  __shared__ float Tq[S * S], Tr[S * S];
+  for (int i = threadIdx.x; i < S * S; i += 256) {
+    Tq[i] = a.qt0 ? a.qt0[i] : 0.0f;
+    Tr[i] = a.rate ? a.rate[i] : 0.0f;
+  }
+  __syncthreads();
+  const int64_t R = (int64_t)a.N * a.D;
+  const int64_t row0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  int n_changed = 0, n_j1 = 0, n_j2 = 0;
+  if (row0 < R) {
+    float L[4 * S], RB[MODE == MODE_RATES ? 4 * S : 1];
+    int X[4], XB[4], XO[4];
+    const bool full = row0 + 3 < R;
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const float4 v = *(const float4*)(a.logits + (size_t)row0 * S + 4 * i);
+        L[4 * i] = v.x; L[4 * i + 1] = v.y; L[4 * i + 2] = v.z; L[4 * i + 3] = v.w;
+      }
+      const int4 xv4 = *(const int4*)(a.x + row0);
+      X[0] = xv4.x; X[1] = xv4.y; X[2] = xv4.z; X[3] = xv4.w;
+      if (a.x_base) { const int4 b4 = *(const int4*)(a.x_base + row0); XB[0] = b4.x; XB[1] = b4.y; XB[2] = b4.z; XB[3] = b4.w; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t rc = row0 + r < R ? row0 + r : R - 1;
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) L[r * S + s_] = a.logits[(size_t)rc * S + s_];
+        X[r] = a.x[rc];
+        if (a.x_base) XB[r] = a.x_base[rc];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + r;
+      const bool live = row < R;
+      const int64_t rowc = live ? row : R - 1;
+      const int xcur = min(max(X[r], 0), S - 1);
+      const int xv = a.x_base ? min(max(XB[r], 0), S - 1) : xcur;
+      XO[r] = xcur;
+      float rr[S], ratio[S], l[S], e[S];
+      float m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < S; ++k) { l[k] = L[r * S + k]; m = fmaxf(m, l[k]); }
+      float z = 0.0f;
+#pragma unroll
+      for (int k = 0; k < S; ++k) { e[k] = expf(l[k] - m); z += e[k]; }
+      if (a.branch == CTDD_BRANCH_CTELBO) {
+        float w[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) { w[k] = (e[k] / z) / (Tq[k * S + xv] + a.eps); ratio[k] = 0.0f; }
+#pragma unroll
+        for (int s0 = 0; s0 < S; ++s0)
+#pragma unroll
+          for (int k = 0; k < S; ++k) ratio[k] = fmaf(w[s0], Tq[s0 * S + k], ratio[k]);
+#pragma unroll
+        for (int k = 0; k < S; ++k) rr[k] = (a.beta * Tr[k * S + xv]) * ratio[k];
+      } else {
+        float ll[S];
+        const float logz = logf(z);
+        if (a.logit_type == CTDD_LOGIT_DIRECT) {
+#pragma unroll
+          for (int k = 0; k < S; ++k) ll[k] = l[k] - m - logz;
+        } else if (a.logit_type == CTDD_LOGIT_REVERSE_PROB) {
+          float acc[S];
+#pragma unroll
+          for (int k = 0; k < S; ++k) acc[k] = 0.0f;
+#pragma unroll
+          for (int s0 = 0; s0 < S; ++s0) {
+            const float ps = e[s0] / z;
+#pragma unroll
+            for (int k = 0; k < S; ++k) acc[k] = fmaf(ps, Tq[s0 * S + k], acc[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < S; ++k) ll[k] = logf(acc[k] + 1e-35f);
+        } else {
+          float mx[S], sm[S];
+#pragma unroll
+          for (int k = 0; k < S; ++k) { mx[k] = -INFINITY; sm[k] = 0.0f; }
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int s0 = 0; s0 < S; ++s0) {
+              const float lp = l[s0] - m - logz;
+#pragma unroll
+              for (int k = 0; k < S; ++k) {
+                const float q = Tq[s0 * S + k];
+                const float t = lp + (q <= 1e-35f ? -1e9f : logf(q));
+                if (pass == 0) mx[k] = fmaxf(mx[k], t);
+                else sm[k] += expf(t - mx[k]);
+              }
+            }
+#pragma unroll
+          for (int k = 0; k < S; ++k) ll[k] = mx[k] + logf(sm[k]);
+        }
+        float ll_xt = ll[0];
+#pragma unroll
+        for (int k = 1; k < S; ++k) ll_xt = (k == xv) ? ll[k] : ll_xt;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+          ratio[k] = expf(ll[k] - ll_xt);
+          rr[k] = ratio[k] * (a.beta * Tr[xv * S + k]);
+        }
+      }
+      if (MODE == MODE_RATES) {                              // (L is dead from here: the rates / ratios of the four rows go out as S 16-byte stores)
+#pragma unroll
+        for (int k = 0; k < S; ++k) { L[r * S + k] = rr[k]; RB[r * S + k] = ratio[k]; }
+        continue;
+      }
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        if (a.flags & CTDD_STEP_CORRECTOR) rr[k] += a.beta * Tr[xv * S + k];
+        if (k == xv) rr[k] = 0.0f;
+      }
+      const int base = xv;
+      if (MODE == MODE_MIDPOINT) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) acc += rr[k] * (float)(k - xv);
+        XO[r] = min(max(xv + (int)rintf(a.h * acc), 0), S - 1);
+        continue;
+      }
+      if (MODE == MODE_LBJF) {
+        float off = 0.0f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) off += rr[k];
+        const float diag = fmaxf(1.0f - a.h * off, 0.0f);
+        float P[S], tot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) { P[k] = (k == xv) ? diag : rr[k] * a.h; tot += P[k]; }
+        float lg[S], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < S; ++k) { lg[k] = logf(P[k] / tot + 1e-35f); mx = fmaxf(mx, lg[k]); }
+        float se = 0.0f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) se += expf(lg[k] - mx);
+        const float lse = mx + logf(se);
+        float pr[S], mx2 = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < S; ++k) { lg[k] -= lse; mx2 = fmaxf(mx2, lg[k]); }
+        float se2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) { pr[k] = expf(lg[k] - mx2); se2 += pr[k]; }
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+          pr[k] /= se2;
+          if (live && a.out_a) a.out_a[(size_t)row * S + k] = pr[k];
+          float Ev;
+          if (a.E) Ev = a.E[(size_t)rowc * S + k];
+          else Ev = -logf(u01(philox_row(a.seed, a.offset, (uint64_t)rowc, (uint32_t)k).x));
+          const float v = pr[k] / Ev;
+          if (v > best || (v == best && k < bi)) { best = v; bi = k; }
+        }
+        XO[r] = bi;
+        if (live && bi != xv) ++n_changed;
+        continue;
+      }
+      // ---- MODE_TAULEAP
+      float T = 0.0f;
+#pragma unroll
+      for (int k = 0; k < S; ++k) T += rr[k];
+      const float Lam = T * a.h;
+      const bool ordinal = a.flags & CTDD_STEP_ORDINAL;
+      int jump = 0, njumps = 0;
+      if (Lam > 0.0f && Lam <= SUPERPOSE_MAX_LAMBDA) {
+        PhiloxStream rng(a.seed, a.offset, (uint64_t)rowc, 0u);
+        const int K = poisson_row(Lam, rng);
+        njumps = K;
+        if (K > 0 && (ordinal || K == 1)) {
+          float c[S], carry = 0.0f;
+#pragma unroll
+          for (int k = 0; k < S; ++k) { c[k] = rr[k] + carry; carry = c[k]; }
+          for (int j = 0; j < K; ++j) {
+            const float target = rng.next() * T;
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) cnt += (c[k] <= target) ? 1 : 0;
+            jump += min(cnt, S - 1) - base;
+          }
+        }
+      } else if (Lam > SUPERPOSE_MAX_LAMBDA) {
+        int cnt = 0;
+        long long jl = 0;
+#pragma unroll
+        for (int k = 0; k < S; k += 4) {
+          const float r1 = k + 1 < S ? rr[k + 1] : 0.0f, r2 = k + 2 < S ? rr[k + 2] : 0.0f, r3 = k + 3 < S ? rr[k + 3] : 0.0f;
+          const int b = k >> 2;
+          const u4 blk = philox_row(a.seed, a.offset, (uint64_t)rowc, DENSE_DRAW0 + (uint32_t)(b >> 2));
+          const uint32_t w = (b & 3) == 0 ? blk.x : (b & 3) == 1 ? blk.y : (b & 3) == 2 ? blk.z : blk.w;
+          cnt += min(subblock_draw(rr[k], r1, r2, r3, a.h, u01(w), a.seed, a.offset, (uint64_t)rowc, b, base, min(4, S - k), &jl), 1 << 20);
+        }
+        jl = jl > S ? S : (jl < -S ? -S : jl);
+        jump = (ordinal || cnt <= 1) ? (int)jl : 0;
+        njumps = cnt;
+      }
+      const int xn = min(max(xcur + jump, 0), S - 1);
+      XO[r] = xn;
+      if (live) {
+        const bool moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
+        n_changed += moved ? 1 : 0;
+        n_j1 += njumps > 0 ? 1 : 0;
+        n_j2 += njumps > 1 ? 1 : 0;
+      }
+    }
+    if (MODE == MODE_RATES) {
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          *(float4*)(a.out_a + (size_t)row0 * S + 4 * i) = make_float4(L[4 * i], L[4 * i + 1], L[4 * i + 2], L[4 * i + 3]);
+          if (a.out_b) *(float4*)(a.out_b + (size_t)row0 * S + 4 * i) = make_float4(RB[4 * i], RB[4 * i + 1], RB[4 * i + 2], RB[4 * i + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < S; ++k)
+            if (row0 + r < R) {
+              a.out_a[(size_t)(row0 + r) * S + k] = L[r * S + k];
+              if (a.out_b) a.out_b[(size_t)(row0 + r) * S + k] = RB[r * S + k];
+            }
+      }
+    } else {
+      if (full) *(int4*)(a.out_x + row0) = make_int4(XO[0], XO[1], XO[2], XO[3]);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (row0 + r < R) a.out_x[row0 + r] = XO[r];
+      }
+    }
+  }
+  if (MODE != MODE_RATES && MODE != MODE_MIDPOINT && a.out_changed) {   // one atomic per wave and counter
+    n_changed = grp_sum_i(n_changed, 64);
+    if ((threadIdx.x & 63) == 0 && n_changed) atomicAdd(a.out_changed, n_changed);
+    if (MODE == MODE_TAULEAP && (a.flags & CTDD_STEP_COUNT_JUMPS)) {
+      n_j1 = grp_sum_i(n_j1, 64); n_j2 = grp_sum_i(n_j2, 64);
+      if ((threadIdx.x & 63) == 0) { if (n_j1) atomicAdd(a.out_changed + 1, n_j1); if (n_j2) atomicAdd(a.out_changed + 2, n_j2); }
+    }
+  }
+}
+
+template <int S>
+static void launch_small_mode(const StepArgs& a, dim3 g, hipStream_t st) {
+  switch (a.mode) {
+    case MODE_RATES: hipLaunchKernelGGL((k_rows_small<S, MODE_RATES>), g, dim3(256), 0, st, a); break;
+    case MODE_TAULEAP: hipLaunchKernelGGL((k_rows_small<S, MODE_TAULEAP>), g, dim3(256), 0, st, a); break;
+    case MODE_LBJF: hipLaunchKernelGGL((k_rows_small<S, MODE_LBJF>), g, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_rows_small<S, MODE_MIDPOINT>), g, dim3(256), 0, st, a); break;
+  }
+}
+// the fused steps with ONE table for the launch, rates not precomputed, 16-byte aligned buffers
+static bool small_rows_ok(const StepArgs& a) {
+  if (a.S > 8 || a.tidx || a.pre_rates) return false;
+  if (a.mode != MODE_RATES && a.mode != MODE_TAULEAP && a.mode != MODE_LBJF && a.mode != MODE_MIDPOINT) return false;
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+  return al16(a.logits) && al16(a.x) && al16(a.x_base) && al16(a.out_x) && (a.mode != MODE_RATES || (al16(a.out_a) && al16(a.out_b)));
+}
+static int launch_rows_small(const StepArgs& a, void* stream) {
+  const int64_t R = (int64_t)a.N * a.D;
+  const int64_t grid = (R + 1023) / 1024;
+  CTDD_REQUIRE(grid > 0 && grid < (1ll << 31), CTDD_ERANGE, "rows out of range: %lld", (long long)R);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g((unsigned)grid);
+  switch (a.S) {
+    case 2: launch_small_mode<2>(a, g, st); break;
+    case 3: launch_small_mode<3>(a, g, st); break;
+    case 4: launch_small_mode<4>(a, g, st); break;
+    case 5: launch_small_mode<5>(a, g, st); break;
+    case 6: launch_small_mode<6>(a, g, st); break;
+    case 7: launch_small_mode<7>(a, g, st); break;
+    default: launch_small_mode<8>(a, g, st); break;
+  }
+  return finish_launch("k_rows_small");
+}
+
 static int launch_rows(const StepArgs& a0, void* stream) {
+  if (small_rows_ok(a0)) return launch_rows_small(a0, stream);
   StepArgs a = a0;
   int G = 1;
   while (G < a.S && G < 64) G <<= 1;
