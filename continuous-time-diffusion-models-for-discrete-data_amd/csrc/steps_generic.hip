@@ -14,7 +14,7 @@
 namespace ctdd {
 
 enum Mode { MODE_RATES = 0, MODE_LOGPROB = 1, MODE_TAULEAP = 2, MODE_LBJF = 3, MODE_MIDPOINT = 4,
-            MODE_DRAW_ONLY = 5 };
+            MODE_DRAW_ONLY = 5, MODE_EXACT = 6 };
 
 struct StepArgs {
   const float* logits;   // (N,D,S)   [MODE_DRAW_ONLY: the rates themselves]
@@ -196,6 +196,56 @@ __global__ __launch_bounds__(256) void k_rows(const StepArgs a) {
     }
     z = grp_sum(z, G);
 
+    if (a.mode == MODE_EXACT) {
+      // exact one-step posterior (sampling.py:975-1061): post[s] = (sum_s0 p[s0] q_lo[s0][s]) q_step[s][x]  (qt0 = q_{t-h|0},
+      // rate = q_{t|t-h}), normalised, one categorical draw by the exponential race of the LBJF step
+      float acc[EPT];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) acc[k] = 0.0f;
+#pragma unroll
+      for (int k0 = 0; k0 < EPT; ++k0) {
+        for (int j = 0; j < G; ++j) {
+          const int s0 = j + k0 * G;
+          if (s0 >= S) break;
+          const float ps = G == 1 ? e[k0] / z : __shfl(e[k0] / z, gbase + j, WAVE);
+          const float* qrow = qt0 + (size_t)s0 * S;
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            const int s = li + k * G;
+            if (s < S) acc[k] = fmaf(ps, qrow[s], acc[k]);
+          }
+        }
+      }
+      float tot = 0.0f;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int s = li + k * G;
+        acc[k] = s < S ? acc[k] * rate[(size_t)s * S + xv] : 0.0f;
+        tot += acc[k];
+      }
+      tot = grp_sum(tot, G);
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int s = li + k * G;
+        if (s < S) {
+          const float pr = acc[k] / tot;
+          if (live && a.out_a) a.out_a[(size_t)row * S + s] = pr;
+          float Ev;
+          if (a.E) Ev = a.E[(size_t)rowc * S + s];
+          else Ev = -logf(u01(philox_row(a.seed, a.offset, (uint64_t)rowc, (uint32_t)s).x));
+          const float v = pr / Ev;
+          if (v > best || (v == best && s < bi)) { best = v; bi = s; }
+        }
+      }
+      grp_argmax(best, bi, G);
+      if (live && li == 0) {
+        a.out_x[row] = bi;
+        if (a.out_changed && bi != xcur) atomicAdd(a.out_changed, 1);
+      }
+      continue;
+    }
     if (a.branch == CTDD_BRANCH_CTELBO && a.mode != MODE_LOGPROB) {
       // w[s0] = softmax[s0] / (qt0[s0][x] + eps);  ratio[s] = sum_s0 w[s0] qt0[s0][s]
       float w[EPT];
@@ -894,6 +944,18 @@ extern "C" int ctdd_midpoint_predict(int branch, int logit_type, const float* lo
   a.h = (float)(0.5 * (double)h);   // 0.5*h evaluated in double, then cast (sampling.py:437-439)
   a.N = N; a.D = D; a.S = S; a.branch = branch; a.logit_type = logit_type; a.mode = MODE_MIDPOINT;
   a.out_x = out_x;
+  return launch_rows(a, stream);
+}
+
+extern "C" int ctdd_exact_step(const float* logits, const int32_t* x, const float* q_lo, const float* q_step, const float* E,
+                               uint64_t seed, uint64_t offset, int N, int D, int S, int32_t* out_x, float* out_probs,
+                               int32_t* out_changed, void* stream) {
+  if (int rc = check_common(logits, x, N, D, S)) return rc;
+  CTDD_REQUIRE(q_lo && q_step && out_x, CTDD_EINVAL, "exact step: null table / output");
+  StepArgs a{};
+  a.logits = logits; a.x = x; a.qt0 = q_lo; a.rate = q_step; a.E = E; a.seed = seed; a.offset = offset; a.N = N; a.D = D; a.S = S;
+  a.branch = CTDD_BRANCH_CRM; a.logit_type = CTDD_LOGIT_DIRECT; a.mode = MODE_EXACT;
+  a.out_x = out_x; a.out_a = out_probs; a.out_changed = out_changed;
   return launch_rows(a, stream);
 }
 

@@ -32,7 +32,7 @@ namespace ctdd {
 
 // mirror of the struct in steps_generic.hip (kept in sync by hand; both files are small)
 enum Mode { MODE_RATES = 0, MODE_LOGPROB = 1, MODE_TAULEAP = 2, MODE_LBJF = 3, MODE_MIDPOINT = 4,
-            MODE_DRAW_ONLY = 5 };
+            MODE_DRAW_ONLY = 5, MODE_EXACT = 6 };
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;

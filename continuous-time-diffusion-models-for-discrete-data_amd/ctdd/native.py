@@ -40,6 +40,7 @@ _SIGS = {
     "ctdd_tauleap_draw": ([_P, _P, _P, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
     "ctdd_tauleap_step": ([_I, _I, _P, _P, _P, _P, _P, _F, _F, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
     "ctdd_lbjf_step": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _U32, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_exact_step": ([_P, _P, _P, _P, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_midpoint_predict": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _P, _P], _I),
     "ctdd_lbjf_from_rates": ([_P, _P, _F, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_midpoint_from_rates": ([_P, _P, _F, _I, _I, _I, _P, _P], _I),
@@ -219,6 +220,18 @@ def lbjf_step(branch, logit_type, logits, x, qt0, base_rate, beta, eps, h, flags
                                float(h), int(flags), _ptr(E, f32, "E"), seed, offset, N, D, S, _ptr(out), _ptr(probs),
                                _ptr(changed, i32, "changed"), _stream())
     _check(rc, "ctdd_lbjf_step")
+    return (out, probs) if want_probs else out
+
+
+def exact_step(logits, x, q_lo, q_step, E=None, seed=0, offset=0, want_probs=False, changed=None):
+    """ExactSampling step: x_new ~ Categorical((softmax(logits) @ q_lo) * q_step[:, x]) per dimension (K5-style contraction +
+    exponential race in one launch)."""
+    N, D, S = logits.shape
+    out = torch.empty((N, D), dtype=i32, device=x.device)
+    probs = torch.empty_like(logits) if want_probs else None
+    rc = load().ctdd_exact_step(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(q_lo, f32, "q_lo"), _ptr(q_step, f32, "q_step"),
+                                _ptr(E, f32, "E"), seed, offset, N, D, S, _ptr(out), _ptr(probs), _ptr(changed, i32, "changed"), _stream())
+    _check(rc, "ctdd_exact_step")
     return (out, probs) if want_probs else out
 
 

@@ -340,8 +340,8 @@ class ExactSampling(_GridSampler):
     """Exact one-step posterior sampling for SDDM models (sampling.py:975-1061):
     x_{t-h}^d ~ sum_{x0} p_theta(x0 | x_t^{\\d}) q_{t-h|0}(.|x0) q_{t|t-h}(x_t^d | .)   per dimension.
     The (N,D,S,S) log-sum-exp of the reference is the matrix product
-    softmax(logits) @ q_{t-h|0} times the column x_t of q_{t|t-h}; the categorical draw is the
-    exponential race of the K2 kernel's rule on device-resident probabilities."""
+    softmax(logits) @ q_{t-h|0} times the column x_t of q_{t|t-h}; contraction, normalisation and the categorical
+    draw (exponential race, the K7 rule) are one HIP launch per step: `ctdd_exact_step`."""
 
     def __init__(self, cfg):
         super().__init__(cfg)
@@ -358,18 +358,16 @@ class ExactSampling(_GridSampler):
             t_lo = torch.from_numpy(ts[:-1] - (ts[:-1] - ts[1:])).to(torch.float32)
             q_lo = pr.tables(t_lo, want_qt0=True)[0]                      # q_{t-h|0}  (steps,S,S)
             q_step = pr.transit_between(t_lo, t_hi)                       # q_{t|t-h}  (steps,S,S)
-            change = torch.zeros(self.num_steps, device=dev)
+            q_lo, q_step = q_lo.contiguous(), q_step.contiguous()
+            x = x.to(torch.int32).contiguous()
+            moved = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
             for i in range(self.num_steps):
                 t_ones = self._t_ones(t_hi, i, N, dev)
-                p0t = torch.softmax(model(x, t_ones).float(), dim=2)      # (N,D,S)
-                post = (p0t @ q_lo[i]) * q_step[i].t()[x]                 # sum_x0 p(x0) q(s|x0) * q_{t|t-h}(x_t|s)
-                probs = (post / post.sum(-1, keepdim=True)).contiguous().view(1, N * self.D, self.S)
-                # one categorical draw per row: table = the row itself (tidx = row id is not needed:
-                # feed rows as a (1, R, S) table indexed by x0 = row) -- use the exponential race directly
-                E = -torch.log(native.philox_uniform(key, i, N * self.D, (self.S + 3) // 4, dev)[:, : self.S])
-                x_new = torch.argmax(probs[0] / E, dim=-1).view(N, self.D)
-                change[i] = (x_new != x).float().mean()
-                x = x_new
+                logits = model(x.long(), t_ones).float().contiguous()
+                # softmax, the S x S contraction with q_{t-h|0}, the column x_t of q_{t|t-h}, normalisation and the categorical
+                # draw (exponential race on Philox(key, i, row, s)) in ONE launch: ctdd_exact_step
+                x = native.exact_step(logits, x, q_lo[i], q_step[i], None, key, i, changed=moved[i:i + 1])
+            change = moved.float() / float(N * self.D)
             return x.cpu().numpy().astype(int), change.cpu().tolist()
 
 

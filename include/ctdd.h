@@ -132,6 +132,14 @@ int ctdd_lbjf_step(int branch, int logit_type, const float* logits, const int32_
                    int N, int D, int S, int32_t* out_x, float* out_probs, int32_t* out_changed,
                    void* stream);
 
+/* ExactSampling step (lib/sampling/sampling.py:975-1061): per dimension
+ * post[s] = (sum_x0 softmax(logits)[x0] q_lo[x0][s]) * q_step[s][x],  q_lo = q_{t-h|0}, q_step = q_{t|t-h}  (S,S each),
+ * x_new ~ Categorical(post / sum post) by the exponential race of K7 (E (N*D,S) explicit, or NULL: Philox(seed, offset, row, s)).
+ * out_probs (N,D,S) and out_changed (count of dimensions that moved) may be NULL. */
+int ctdd_exact_step(const float* logits, const int32_t* x, const float* q_lo, const float* q_step, const float* E,
+                    uint64_t seed, uint64_t offset, int N, int D, int S, int32_t* out_x, float* out_probs,
+                    int32_t* out_changed, void* stream);
+
 /* K8  midpoint predictor (lib/sampling/sampling.py:417-453):
  * x' = clip(x + round_half_even(0.5*h*sum_s R^_s (s-x)), 0, S-1) with own state excluded. */
 int ctdd_midpoint_predict(int branch, int logit_type, const float* logits, const int32_t* x,

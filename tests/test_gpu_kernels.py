@@ -343,6 +343,45 @@ def test_lbjf_step(nat, kind, S, branch, lt):
     assert torch.equal(out.cpu().long()[decided], ref[decided])
 
 
+@pytest.mark.parametrize("kind,S", [("univar", 3), ("uniform", 3), ("gaussian", 16), ("gaussian", 256)])
+def test_exact_step(nat, kind, S):
+    """ctdd_exact_step (ExactSampling, sampling.py:990-1061) against the oracle's log-space formula
+    logsumexp_x0(log p0t[x0] + log(q_{t-h|0}[x0, s] q_{t|t-h}[s, x_t])) and the same exponential noise."""
+    import torch.nn.functional as F
+    N, D = 3, 70
+    proc = make_process(kind, S)
+    g = torch.Generator().manual_seed(31)
+    logits = torch.randn(N, D, S, generator=g) * 2
+    x = torch.randint(0, S, (N, D), generator=g)
+    t_hi, t_lo = torch.full((1,), 0.6), torch.full((1,), 0.55)
+    q_lo = proc.transition(t_lo)[0]
+    q_step = proc.transit_between(t_lo, t_hi)[0]
+    E = torch.empty(N * D, S).exponential_(1, generator=g)
+    log_p0t = F.log_softmax(logits.double(), dim=2)
+    qq = q_lo.double().view(1, 1, S, S) * q_step.double().t()[x].unsqueeze(-2)                   # [n, d, x0, s]
+    log_prob = torch.logsumexp(log_p0t.unsqueeze(-1) + torch.log(qq), dim=-2).view(-1, S)
+    probs_ref = ops.categorical_probs_from_logits(log_prob.float())
+    vals = probs_ref / E
+    ref = torch.argmax(vals, -1).view(N, D)
+    top2 = torch.topk(vals, 2, dim=-1).values
+    decided = ((top2[:, 0] - top2[:, 1]) > 1e-4 * top2[:, 0]).view(N, D)
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out, probs = nat.exact_step(dev(logits), dev(x, torch.int32), dev(q_lo), dev(q_step), E=dev(E), want_probs=True, changed=cnt)
+    np.testing.assert_allclose(probs.cpu().numpy().reshape(-1, S), probs_ref.numpy(), rtol=2e-4, atol=1e-30)
+    assert decided.float().mean() > 0.99
+    assert torch.equal(out.cpu().long()[decided], ref[decided])
+    assert int(cnt.item()) == int((out.cpu().long() != x).sum())
+    # Philox noise: replay of the (seed, offset, row, s) stream
+    out2 = nat.exact_step(dev(logits), dev(x, torch.int32), dev(q_lo), dev(q_step), seed=7, offset=2)
+    rows = np.arange(N * D, dtype=np.uint64)
+    lo, hi = (rows & 0xFFFFFFFF).astype(np.uint32), (rows >> np.uint64(32)).astype(np.uint32)
+    Eph = np.stack([oph.exp1(oph.philox4x32_10(lo, hi, np.uint32(2), np.uint32(s_), 7, 0)[0]) for s_ in range(S)], -1)
+    v2 = probs_ref / T(Eph)
+    t2 = torch.topk(v2, 2, dim=-1).values
+    dec2 = ((t2[:, 0] - t2[:, 1]) > 1e-4 * t2[:, 0]).view(N, D)
+    assert torch.equal(out2.cpu().long()[dec2], torch.argmax(v2, -1).view(N, D)[dec2])
+
+
 @pytest.mark.parametrize("kind,S,branch,lt", [("univar", 3, 1, "reverse_prob"), ("univar", 2, 1, "direct"),
                                               ("gaussian", 16, 0, "direct")])
 def test_midpoint_predict(nat, kind, S, branch, lt):
