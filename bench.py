@@ -215,6 +215,42 @@ def train_step_timing(batch=64, steps=10, warmup=4):
             "ms_per_step": out, "speedup": round(out["torch_autograd_fp32"] / out["hip_plan_bf16"], 2)}
 
 
+def hollow_train_step_timing(batch=128, steps=10, warmup=4):
+    """One training step of the maze hollow transformer (config_hollow_maze: D = 225, S = 3, E = 128, 2 x 8 blocks, dropout 0.1,
+    ScoreElbo with reverse_prob logits, batch 128): the network forward / backward on the HIP training path
+    (ctdd/hollow_train.py, bf16 GEMM / attention operands) and on torch autograd device ops."""
+    import lib.losses.losses  # noqa: F401
+    import lib.losses.losses_utils as lu
+    import lib.models.model_utils as mu
+    import lib.optimizers.optimizers  # noqa: F401
+    import lib.optimizers.optimizers_utils as ou
+    import lib.training.training  # noqa: F401
+    import lib.training.training_utils as tu
+    from config.maze_config.config_hollow_maze import get_config
+    out = {}
+    for tag, engine in (("hip_bf16", "hip"), ("torch_autograd_fp32", "torch")):
+        cfg = get_config()
+        cfg.device, cfg.model.engine = "cuda", engine
+        torch.manual_seed(0)
+        model = mu.create_model(cfg, torch.device("cuda"))
+        state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+        step, loss = tu.get_train_step(cfg), lu.get_loss(cfg)
+        mb = torch.randint(0, 3, (batch, 1, 15, 15), device="cuda")
+        for _ in range(warmup):
+            step.step(state, loss, mb)
+            state["n_iter"] += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step.step(state, loss, mb)
+            state["n_iter"] += 1
+        torch.cuda.synchronize()
+        out[tag] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        del model, state
+    return {"workload": f"maze hollow-transformer ScoreElbo training step, batch {batch} (Standard.step)", "ms_per_step": out,
+            "speedup": round(out["torch_autograd_fp32"] / out["hip_bf16"], 2)}
+
+
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
     """The CPU oracle (restatement of the reference's CPU path, pinned by tests/golden) doing the
     same tau-leaping step on the host cores: oracle U-Net forward + reverse rates + torch.poisson
@@ -330,6 +366,7 @@ def main():
         }
         if world == 1 and not a.no_train_step:
             line["train_step"] = train_step_timing()
+            line["train_step_hollow"] = hollow_train_step_timing()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, cfg, a.cpu_batch)
         print(json.dumps(line), flush=True)
