@@ -717,6 +717,40 @@ __global__ __launch_bounds__(256) void k_hollow_act(const float* __restrict__ pr
   }
 }
 
+// bf16-only ReLU (+ dropout) for the MLP hidden tensor in the bf16 mode (the fp32 copy of a (rows, mlp_dim) tensor is the
+// largest stream of a block): forward  u = dropout(relu(pre)) (in place allowed);  backward  dpre = du * [u != 0] / (1 - p)
+// -- a dropped or clipped entry of u is exactly 0, so the saved output IS the mask and backward draws no random numbers.
+__global__ __launch_bounds__(256) void k_hollow_relu_bf16(const unsigned short* __restrict__ src, const unsigned short* __restrict__ mask_u,
+                                                         unsigned short* __restrict__ out, int64_t noct, float drop_p,
+                                                         const uint64_t* rng, uint64_t layer) {
+  const float inv_keep = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < noct; v += (int64_t)gridDim.x * 256) {
+    const uint4 in = *(const uint4*)(src + v * 8);
+    const unsigned w[4] = {in.x, in.y, in.z, in.w};
+    unsigned o[4];
+    if (mask_u) {                                                            // backward: src = du, mask_u = saved u
+      const uint4 mu = *(const uint4*)(mask_u + v * 8);
+      const unsigned m[4] = {mu.x, mu.y, mu.z, mu.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a0 = (m[k] & 0x7FFFu) ? __uint_as_float(w[k] << 16) * inv_keep : 0.0f;
+        const float a1 = (m[k] & 0x7FFF0000u) ? __uint_as_float(w[k] & 0xFFFF0000u) * inv_keep : 0.0f;
+        o[k] = ht_pack2(a0, a1);
+      }
+    } else {
+      unsigned keep = 0xFFu;
+      if (drop_p > 0.0f) keep = keep4(rng, layer, (uint64_t)(2 * v), drop_p) | (keep4(rng, layer, (uint64_t)(2 * v + 1), drop_p) << 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a0 = fmaxf(__uint_as_float(w[k] << 16), 0.0f) * ((keep >> (2 * k)) & 1u ? inv_keep : 0.0f);
+        const float a1 = fmaxf(__uint_as_float(w[k] & 0xFFFF0000u), 0.0f) * ((keep >> (2 * k + 1)) & 1u ? inv_keep : 0.0f);
+        o[k] = ht_pack2(a0, a1);
+      }
+    }
+    *(uint4*)(out + v * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // ============================================================================ embedding backward (hollow_networks.py:729-753)
 // x_embed[b][d] = w_in xn[b][d] + b_in feeds l2r[b][d+1] and r2l[b][d-1]:  dxe[b][d] = dl2r[b][d+1] (d <= D-2) + dr2l[b][d-1] (d >= 1)
 // dw_in[e] = sum dxe xn ; db_in[e] = sum dxe
@@ -822,6 +856,17 @@ extern "C" int ctdd_hollow_act(const float* pre, const float* dout, float* out, 
   hipLaunchKernelGGL(k_hollow_act, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pre, dout, out, (unsigned short*)out_bf16, n / 4, act,
                      drop_p, rng, layer);
   return finish_launch("k_hollow_act");
+}
+
+extern "C" int ctdd_hollow_relu_bf16(const void* src, const void* mask_u, void* out, int64_t n, float drop_p, const uint64_t* rng,
+                                     uint64_t layer, void* stream) {
+  CTDD_REQUIRE(src && out && n > 0 && n % 8 == 0, CTDD_EINVAL, "relu (bf16): n=%lld", (long long)n);
+  CTDD_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && (drop_p == 0.0f || mask_u || rng), CTDD_EINVAL, "relu (bf16): dropout %g", (double)drop_p);
+  int64_t g = (n / 8 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_hollow_relu_bf16, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src,
+                     (const unsigned short*)mask_u, (unsigned short*)out, n / 8, drop_p, rng, layer);
+  return finish_launch("k_hollow_relu_bf16");
 }
 
 extern "C" int ctdd_hollow_embed_bwd(const void* args_, void* stream) {

@@ -60,7 +60,8 @@ def lib():
         for name, argt in (("ctdd_hollow_layernorm_bwd", [_P, _P]), ("ctdd_hollow_attention_train", [_P, _P]),
                            ("ctdd_hollow_attention_bwd", [_P, _P]), ("ctdd_hollow_attention_train_bf16", [_P, _P]),
                            ("ctdd_hollow_attention_bwd_bf16", [_P, _P]),
-                           ("ctdd_hollow_act", [_P, _P, _P, _P, _I64, _I, _F, _P, _U64, _P]), ("ctdd_hollow_embed_bwd", [_P, _P])):
+                           ("ctdd_hollow_act", [_P, _P, _P, _P, _I64, _I, _F, _P, _U64, _P]), ("ctdd_hollow_embed_bwd", [_P, _P]),
+                           ("ctdd_hollow_relu_bf16", [_P, _P, _P, _I64, _F, _P, _U64, _P])):
             fn = getattr(l, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -458,7 +459,9 @@ class AttnBlockFn(torch.autograd.Function):
 
 
 class MlpBlockFn(torch.autograd.Function):
-    """h + dropout(fc2(dropout(relu(fc1(LayerNorm(h)))))): one prenorm feed-forward block (hollow_networks.py:343-420)."""
+    """h + dropout(fc2(dropout(relu(fc1(LayerNorm(h)))))): one prenorm feed-forward block (hollow_networks.py:343-420).
+    bf16 mode: the (rows, mlp_dim) hidden tensor and its gradient exist in bf16 only (the fp32 copies were the largest
+    streams of the block); the saved output u = dropout(relu(.)) is its own backward mask."""
 
     @staticmethod
     def forward(ctx, h, ln_w, ln_b, w1, b1, w2, rng, meta):
@@ -467,13 +470,19 @@ class MlpBlockFn(torch.autograd.Function):
         h = h.contiguous()
         z, z_hi = _layernorm(h, None, ln_w, ln_b, None, eps, want_f32=not bf16, want_hi=bf16)
         z_op = (z_hi if bf16 else z).view(R, E)
-        if p_drop > 0.0:
-            pre, _ = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, bf16)
-            u, u_hi = _act(pre, None, 1, p_drop, rng, l1, want_f32=not bf16, want_hi=bf16)
+        if bf16:
+            # ReLU in the GEMM epilogue; with dropout one in-place pass over the bf16 tensor (relu is idempotent)
+            _, u_op = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, True, act=1, want_hi=True, want_f32=False)
+            if p_drop > 0.0:
+                _ck(lib().ctdd_hollow_relu_bf16(u_op.data_ptr(), None, u_op.data_ptr(), u_op.numel(), float(p_drop), rng.data_ptr(), int(l1), _st()),
+                    "ctdd_hollow_relu_bf16")
+            pre = u_op
+        elif p_drop > 0.0:
+            pre, _ = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, False)
+            u_op, _ = _act(pre, None, 1, p_drop, rng, l1)
         else:
-            pre, u_hi = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, bf16, act=1, want_hi=bf16)     # relu(pre): same ReLU mask
-            u = pre
-        u_op = u_hi if bf16 else u
+            pre, _ = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, False, act=1)     # relu(pre): same ReLU mask
+            u_op = pre
         if p_drop > 0.0:
             o, _ = _gemm(u_op, pk2[0], None, None, R, M, E, bf16)
             out = _add(_dropout_(o, p_drop, rng, l2), h.view(R, E))
@@ -491,9 +500,17 @@ class MlpBlockFn(torch.autograd.Function):
         dout = dout.contiguous()
         zw2, zw1, zb1, rep = _zeros(dout.device, (E, M), (M, E), (M, 8), (LN_REPLICAS, 2 * E))
         do = _dropout_(dout.clone(), p_drop, rng, l2) if p_drop > 0.0 else dout
-        du, dw2, _ = _linear_bwd(u_op, w2, do.view(R, E), R, bf16, False, wt=pk2[1], bufs=(zw2, None))
-        dpre, dpre_hi = _act(pre, du, 1, p_drop, rng if p_drop > 0 else None, l1, want_f32=not bf16, want_hi=bf16)
-        dz, dw1, db1 = _linear_bwd(z_op, w1, dpre, R, bf16, True, dy_hi=dpre_hi, wt=pk1[1], bufs=(zw1, zb1))
+        if bf16:
+            do_hi = _cast(do.view(R, E), R, E, E, True)
+            dw2, _ = _wgrad(u_op, do_hi, R, E, E, M, True, False, (zw2, None))
+            _, du_hi = _gemm(do_hi, pk2[1], None, None, R, E, M, True, want_hi=True, want_f32=False)
+            _ck(lib().ctdd_hollow_relu_bf16(du_hi.data_ptr(), u_op.data_ptr(), du_hi.data_ptr(), du_hi.numel(), float(p_drop), None, 0, _st()),
+                "ctdd_hollow_relu_bf16")
+            dz, dw1, db1 = _linear_bwd(z_op, w1, None, R, True, True, dy_hi=du_hi, wt=pk1[1], bufs=(zw1, zb1))
+        else:
+            du, dw2, _ = _linear_bwd(u_op, w2, do.view(R, E), R, False, False, wt=pk2[1], bufs=(zw2, None))
+            dpre, _ = _act(pre, du, 1, p_drop, rng if p_drop > 0 else None, l1)
+            dz, dw1, db1 = _linear_bwd(z_op, w1, dpre, R, False, True, wt=pk1[1], bufs=(zw1, zb1))
         dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone(), rep=rep)
         return dh, dg, dbeta, dw1, db1, dw2, None, None
 

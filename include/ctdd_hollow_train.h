@@ -48,6 +48,12 @@ int ctdd_hollow_attention_bwd_bf16(const void* attn_train_args, void* stream);
 int ctdd_hollow_act(const float* pre, const float* dout, float* out, void* out_bf16, int64_t n, int act, float drop_p,
                     const uint64_t* rng, uint64_t layer, void* stream);
 
+/* bf16-only ReLU (+ dropout) of the MLP hidden tensor (bf16 mode), n % 8 == 0:
+ * mask_u == NULL: out = dropout(relu(src))  (Philox masks as ctdd_hollow_act on the same element indices; in place allowed);
+ * mask_u != NULL: out = src * [mask_u != 0] / (1 - p)  -- the backward, with the saved forward output as the mask. */
+int ctdd_hollow_relu_bf16(const void* src, const void* mask_u, void* out, int64_t n, float drop_p, const uint64_t* rng,
+                          uint64_t layer, void* stream);
+
 /* gradient of the input embedding Linear(1 -> E) (hollow_networks.py:740-742): dw, db [E] atomically accumulated */
 typedef struct { const int64_t* x64; const int32_t* x32; const float* dl2r; const float* dr2l; int B, D, E, S; float* dw; float* db; } ctdd_hollow_embed_bwd_args;
 int ctdd_hollow_embed_bwd(const void* embed_bwd_args, void* stream);
