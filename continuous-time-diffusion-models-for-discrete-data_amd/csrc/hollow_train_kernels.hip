@@ -12,6 +12,9 @@
 // The linear layers' gradients run on the U-Net kernels (ctdd_unet_conv* with transposed weights, ctdd_unet_wgrad kind 1x1).
 // Dropout masks are Philox(seed, step * 4096 + layer, element) (common.hpp), regenerated in backward.
 #include "common.hpp"
+#ifndef CTDD_ATT_NW
+#define CTDD_ATT_NW 4      // waves per workgroup of the matrix-core attention kernels
+#endif
 
 namespace ctdd {
 
@@ -27,6 +30,10 @@ __device__ inline unsigned short ht_bf16(float a) {
   return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b)) & 0xFFFFu);
 }
 // keep flags of elements 4e .. 4e+3 of a tensor under dropout rate p
+__device__ inline unsigned keep4v(uint64_t seed, uint64_t ctr, uint64_t quad, float p) {      // (seed, step * 4096 + layer) preloaded
+  const u4 r = philox_row(seed, ctr, quad, 0x44524F50u);
+  return (u01(r.x) >= p ? 1u : 0u) | (u01(r.y) >= p ? 2u : 0u) | (u01(r.z) >= p ? 4u : 0u) | (u01(r.w) >= p ? 8u : 0u);
+}
 __device__ inline unsigned keep4(const uint64_t* rng, uint64_t layer, uint64_t quad, float p) {
   const u4 r = philox_row(rng[0], rng[1] * 4096u + layer, quad, 0x44524F50u);
   return (u01(r.x) >= p ? 1u : 0u) | (u01(r.y) >= p ? 2u : 0u) | (u01(r.z) >= p ? 4u : 0u) | (u01(r.w) >= p ? 8u : 0u);
@@ -380,29 +387,61 @@ __device__ inline bool chunk_full(int mode, int Tq, int Tk, int j0, int q0) {   
   if (mode == 1) return j0 >= q0 + 31;
   return (j0 >= 1 && j0 + 31 <= Tq && j0 + 30 <= q0) || (j0 > Tq && j0 - Tq - 1 >= q0 + 31);
 }
+// The attention mask of the matrix-core kernels, branch-free with the (launch-uniform) mode as a template argument: a
+// per-register `if` chain on the run-time mode made the compiler build every lane mask with scalar and / or / branch
+// sequences -- ~1700 instructions per 32 x 32 tile, an order of magnitude above the softmax arithmetic.
+template <int MODE>
+__device__ inline bool allowed_t(int Tq, int i, int j) {
+  if (MODE == 0) return j <= i;
+  if (MODE == 1) return j >= i;
+  return (j == 0) | ((j <= Tq) & (j - 1 <= i)) | ((j > Tq) & (j - Tq - 1 >= i));
+}
+// query-side tile: lane = query i, register r = key jb + (r & 3) + 8 (r >> 2)  (jb = chunk start + 4 kh)
+template <int MODE>
+__device__ inline void mask_tile_q(f32x16t& s, int Tq, int Tk, int i, bool qok, int jb) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = jb + (r & 3) + 8 * (r >> 2);
+    const bool ok = qok & (j < Tk) & allowed_t<MODE>(Tq, i, j);
+    s[r] = ok ? s[r] : -INFINITY;
+  }
+}
+// key-side tile: lane = key j, register r = query ib + (r & 3) + 8 (r >> 2); returns the 16 flags
+template <int MODE>
+__device__ inline unsigned mask_bits_kv(int Tq, int j, bool kok, int ib) {
+  unsigned m = 0u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = ib + (r & 3) + 8 * (r >> 2);
+    const bool ok = kok & (i < Tq) & allowed_t<MODE>(Tq, i, j);
+    m |= ok ? (1u << r) : 0u;
+  }
+  return m;
+}
 constexpr int RLD16 = 8, TLD = 40;                  // row-major rows: HD + 8 bf16; transposed rows: 32 + 8
 
 // Staging of a chunk of 32 rows of TWO fp32 matrices [row][HD] as bf16, split in a fetch (global -> registers, issued a chunk
 // ahead so that the loads fly under the previous chunk's products) and a store (registers -> LDS: row-major R and / or
 // transposed T [dim][row]).  256 threads: item = (matrix, row, four dims); HD / 16 items per thread.
-template <int HD>
+template <int HD, int NTH>
 struct Stage2 {
-  static constexpr int NU = HD / 16, ITEMS = 32 * HD / 4;
+  static constexpr int NU = (2 * 32 * HD / 4 + NTH - 1) / NTH, ITEMS = 32 * HD / 4;
   float4 v[NU];
   __device__ inline void fetch(const float* m0, int64_t rs0, const float* m1, int64_t rs1, int r0, int rmax) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int idx = threadIdx.x + 256 * u, mat = idx / ITEMS, r = idx % ITEMS;
+      const int idx = threadIdx.x + NTH * u, mat = idx / ITEMS, r = idx % ITEMS;
       const int rr = r / (HD / 4), c4 = (r % (HD / 4)) * 4;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + rr < rmax) v[u] = *(const float4*)((mat ? m1 : m0) + (size_t)(r0 + rr) * (mat ? rs1 : rs0) + c4);
+      if (idx < 2 * ITEMS && r0 + rr < rmax) v[u] = *(const float4*)((mat ? m1 : m0) + (size_t)(r0 + rr) * (mat ? rs1 : rs0) + c4);
     }
   }
   __device__ inline void store(float scale0, unsigned short* R0, unsigned short* T0, unsigned short* R1, unsigned short* T1) const {
     constexpr int RLD = HD + RLD16;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int idx = threadIdx.x + 256 * u, mat = idx / ITEMS, r = idx % ITEMS;
+      const int idx = threadIdx.x + NTH * u, mat = idx / ITEMS, r = idx % ITEMS;
+      if (idx >= 2 * ITEMS) continue;
       const int rr = r / (HD / 4), c4 = (r % (HD / 4)) * 4;
       const float sc = mat ? 1.0f : scale0;
       const unsigned p01 = ht_pack2(v[u].x * sc, v[u].y * sc), p23 = ht_pack2(v[u].z * sc, v[u].w * sc);
@@ -424,15 +463,15 @@ __device__ inline bf16x8t tfrag(const unsigned short* T, int col, int kh, int s_
 }
 
 // MODE_BWD false: forward with dropout, writes out (+ bf16 copy) and the row statistics;  true: D_i = dO.O and dQ
-template <int HD, bool BWD>
-__global__ __launch_bounds__(256) void k_hollow_attn_q_mfma(const AttnTrainArgs a) {
+template <int HD, bool BWD, int NW>      // NW waves = 32 NW queries per workgroup
+__global__ __launch_bounds__(64 * NW) void k_hollow_attn_q_mfma(const AttnTrainArgs a) {
   constexpr int KS = HD / 16, RLD = HD + RLD16;
   __shared__ __attribute__((aligned(16))) unsigned short Kr[32 * RLD];          // K rows [key][dim]
   __shared__ __attribute__((aligned(16))) unsigned short Vr[BWD ? 32 * RLD : 8];   // V rows (backward: dP^T = V dO^T)
   __shared__ __attribute__((aligned(16))) unsigned short Tt[32 * TLD];          // forward: V^T;  backward: K^T   ([dim][key], dims >= HD zero)
   const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, kh = lane >> 5;
-  const int q0 = blockIdx.x * 128 + wave * 32, i = q0 + col;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32, i = q0 + col;
   const bool qok = i < a.Tq;
   bf16x8t qf[KS], dof[KS];
   row_frags<HD>(a.q + (size_t)b * a.q_bs + (size_t)(qok ? i : 0) * a.q_rs + h * HD, qok, a.scale, kh, qf);
@@ -455,14 +494,15 @@ __global__ __launch_bounds__(256) void k_hollow_attn_q_mfma(const AttnTrainArgs 
   const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
   const uint64_t qrow = (((uint64_t)b * a.H + h) * a.Tq + (qok ? i : 0)) * quads;
+  const uint64_t rseed = a.drop_p > 0.0f ? a.rng[0] : 0, rctr = a.drop_p > 0.0f ? a.rng[1] * 4096u + a.layer : 0;   // (once: not per chunk)
   f32x16t oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
-  for (int idx = threadIdx.x; idx < 32 * TLD / 2; idx += 256) ((unsigned*)Tt)[idx] = 0u;   // (rows >= HD stay zero)
-  const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tq) - 1, mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;
+  for (int idx = threadIdx.x; idx < 32 * TLD / 2; idx += 64 * NW) ((unsigned*)Tt)[idx] = 0u;   // (rows >= HD stay zero)
+  const int wlo = blockIdx.x * (32 * NW), whi = min(wlo + 32 * NW, a.Tq) - 1, mylo = q0, myhi = min(q0 + 32, a.Tq) - 1;
   const float* kb = a.k + (size_t)b * a.k_bs + h * HD;
   const float* vb = a.v + (size_t)b * a.v_bs + h * HD;
-  Stage2<HD> stg;
+  Stage2<HD, 64 * NW> stg;
   auto next_visible = [&](int jc) {                                             // (uniform over the workgroup)
     while (jc < a.Tk && !chunk_any(a.mode, a.Tq, a.Tk, jc, wlo, whi)) jc += 32;
     return jc;
@@ -491,18 +531,15 @@ __global__ __launch_bounds__(256) void k_hollow_attn_q_mfma(const AttnTrainArgs 
     }
     const bool full = chunk_full(a.mode, a.Tq, a.Tk, j0, q0);
     if (!full) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const bool ok = qok && j < a.Tk && attn_allowed(a.mode, a.Tq, i, j);
-        sacc[r] = ok ? sacc[r] : -INFINITY;
-      }
+      if (a.mode == 0) mask_tile_q<0>(sacc, a.Tq, a.Tk, i, qok, j0 + 4 * kh);
+      else if (a.mode == 1) mask_tile_q<1>(sacc, a.Tq, a.Tk, i, qok, j0 + 4 * kh);
+      else mask_tile_q<2>(sacc, a.Tq, a.Tk, i, qok, j0 + 4 * kh);
     }
     unsigned keep = 0xFFFFu;                                                     // bit r: probability r survives the dropout
     if (a.drop_p > 0.0f) {
       keep = 0u;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) keep |= keep4(a.rng, a.layer, qrow + (uint64_t)((j0 + 8 * g + 4 * kh) >> 2), a.drop_p) << (4 * g);
+      for (int g = 0; g < 4; ++g) keep |= keep4v(rseed, rctr, qrow + (uint64_t)((j0 + 8 * g + 4 * kh) >> 2), a.drop_p) << (4 * g);
     }
     unsigned pw[8];
     if (!BWD) {
@@ -557,26 +594,27 @@ __global__ __launch_bounds__(256) void k_hollow_attn_q_mfma(const AttnTrainArgs 
 }
 
 // dK, dV: wave = 32 keys (lane = key), loop over chunks of 32 queries
-template <int HD>
-__global__ __launch_bounds__(256) void k_hollow_attn_kv_mfma(const AttnTrainArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void k_hollow_attn_kv_mfma(const AttnTrainArgs a) {
   constexpr int KS = HD / 16, RLD = HD + RLD16;
   __shared__ __attribute__((aligned(16))) unsigned short Qr[32 * RLD], Dr[32 * RLD];     // scale Q rows, dO rows  [query][dim]
   __shared__ __attribute__((aligned(16))) unsigned short Qt[32 * TLD], Dt[32 * TLD];     // their transposes [dim][query]
   __shared__ float Sm[32], Sl[32], Sd[32];                                                // per query: max, 1 / sum, D_i
   const int b = blockIdx.z, h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, kh = lane >> 5;
-  const int k0 = blockIdx.x * 128 + wave * 32, j = k0 + col;
+  const int k0 = blockIdx.x * (32 * NW) + wave * 32, j = k0 + col;
   const bool kok = j < a.Tk;
   bf16x8t kf[KS], vf[KS];
   row_frags<HD>(a.k + (size_t)b * a.k_bs + (size_t)(kok ? j : 0) * a.k_rs + h * HD, kok, 1.0f, kh, kf);
   row_frags<HD>(a.v + (size_t)b * a.v_bs + (size_t)(kok ? j : 0) * a.v_rs + h * HD, kok, 1.0f, kh, vf);
   const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
+  const uint64_t rseed = a.drop_p > 0.0f ? a.rng[0] : 0, rctr = a.drop_p > 0.0f ? a.rng[1] * 4096u + a.layer : 0;
   f32x16t kacc, vacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { kacc[r] = 0.0f; vacc[r] = 0.0f; }
-  for (int idx = threadIdx.x; idx < 32 * TLD / 2; idx += 256) { ((unsigned*)Qt)[idx] = 0u; ((unsigned*)Dt)[idx] = 0u; }
-  const int wlo = blockIdx.x * 128, whi = min(wlo + 128, a.Tk) - 1, mylo = k0, myhi = min(k0 + 32, a.Tk) - 1;
+  for (int idx = threadIdx.x; idx < 32 * TLD / 2; idx += 64 * NW) { ((unsigned*)Qt)[idx] = 0u; ((unsigned*)Dt)[idx] = 0u; }
+  const int wlo = blockIdx.x * (32 * NW), whi = min(wlo + 32 * NW, a.Tk) - 1, mylo = k0, myhi = min(k0 + 32, a.Tk) - 1;
   // does the chunk of queries i0.. see any key of [lo, hi]?  (the mask read from the key side)
   auto q_any = [&](int i0, int lo, int hi) {
     const int il = min(i0 + 32, a.Tq) - 1;
@@ -591,7 +629,7 @@ __global__ __launch_bounds__(256) void k_hollow_attn_kv_mfma(const AttnTrainArgs
   const float* qb = a.q + (size_t)b * a.q_bs + h * HD;
   const float* db = a.d_out + (size_t)b * a.Tq * a.out_rs + h * HD;
   const float* sb = a.stats + ((size_t)b * a.H + h) * a.Tq * 4;
-  Stage2<HD> stg;
+  Stage2<HD, 64 * NW> stg;
   float pm = 0.0f, pl = 0.0f, pd = 0.0f;                                         // the chunk's row statistics, fetched ahead (threads 0..31)
   auto next_visible = [&](int ic) {                                             // (uniform over the workgroup)
     while (ic < a.Tq && !q_any(ic, wlo, whi)) ic += 32;
@@ -638,7 +676,7 @@ __global__ __launch_bounds__(256) void k_hollow_attn_kv_mfma(const AttnTrainArgs
       for (int g = 0; g < 4; ++g) {
         const int i = i0 + (col & 3) + 8 * g + 4 * kh;
         const uint64_t quad = (((uint64_t)b * a.H + h) * a.Tq + (uint64_t)min(i, a.Tq - 1)) * quads + (uint64_t)(min(j, a.Tk - 1) >> 2);
-        mine |= keep4(a.rng, a.layer, quad, a.drop_p) << (4 * g);
+        mine |= keep4v(rseed, rctr, quad, a.drop_p) << (4 * g);
       }
       keep = 0u;
 #pragma unroll
@@ -648,14 +686,16 @@ __global__ __launch_bounds__(256) void k_hollow_attn_kv_mfma(const AttnTrainArgs
         for (int g = 0; g < 4; ++g) keep |= ((w >> (4 * g + (j & 3))) & 1u) << (4 * g + u);
       }
     }
+    const unsigned okm = a.mode == 0 ? mask_bits_kv<0>(a.Tq, j, kok, i0 + 4 * kh)
+                       : a.mode == 1 ? mask_bits_kv<1>(a.Tq, j, kok, i0 + 4 * kh) : mask_bits_kv<2>(a.Tq, j, kok, i0 + 4 * kh);
     unsigned pw[8], dw[8];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       float p[2], ds[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int il = ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * kh, i = i0 + il;
-        const bool ok = kok && i < a.Tq && attn_allowed(a.mode, a.Tq, i, j);
+        const int il = ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * kh;
+        const bool ok = (okm >> (r + e)) & 1u;
         const float pr = ok ? __expf(sacc[r + e] - Sm[il]) * Sl[il] : 0.0f;
         const bool kp = (keep >> (r + e)) & 1u;
         p[e] = kp ? pr * inv_keep : 0.0f;
@@ -819,9 +859,10 @@ extern "C" int ctdd_hollow_attention_bwd(const void* args_, void* stream) {
 }
 #undef HD_DISPATCH
 
-#define HD_DISPATCH_MFMA(KERNEL16, KERNEL32, GRIDX)                                                          \
-  if (a.hd == 16) hipLaunchKernelGGL(KERNEL16, dim3(GRIDX, a.H, a.B), dim3(256), 0, (hipStream_t)stream, a); \
-  else hipLaunchKernelGGL(KERNEL32, dim3(GRIDX, a.H, a.B), dim3(256), 0, (hipStream_t)stream, a);
+constexpr int ATT_NW = CTDD_ATT_NW;
+#define HD_DISPATCH_MFMA(KERNEL16, KERNEL32, GRIDX)                                                                  \
+  if (a.hd == 16) hipLaunchKernelGGL(KERNEL16, dim3(GRIDX, a.H, a.B), dim3(64 * ATT_NW), 0, (hipStream_t)stream, a); \
+  else hipLaunchKernelGGL(KERNEL32, dim3(GRIDX, a.H, a.B), dim3(64 * ATT_NW), 0, (hipStream_t)stream, a);
 static int attn_check_mfma(const AttnTrainArgs& a) {
   if (int rc = attn_check(a)) return rc;
   CTDD_REQUIRE(a.hd == 16 || a.hd == 32, CTDD_ERANGE, "attention (training, matrix cores): head dimension %d (16 or 32)", a.hd);
@@ -832,7 +873,7 @@ static int attn_check_mfma(const AttnTrainArgs& a) {
 extern "C" int ctdd_hollow_attention_train_bf16(const void* args_, void* stream) {
   const AttnTrainArgs& a = *(const AttnTrainArgs*)args_;
   if (int rc = attn_check_mfma(a)) return rc;
-  HD_DISPATCH_MFMA((k_hollow_attn_q_mfma<16, false>), (k_hollow_attn_q_mfma<32, false>), (a.Tq + 127) / 128)
+  HD_DISPATCH_MFMA((k_hollow_attn_q_mfma<16, false, ATT_NW>), (k_hollow_attn_q_mfma<32, false, ATT_NW>), (a.Tq + 32 * ATT_NW - 1) / (32 * ATT_NW))
   return finish_launch("k_hollow_attn_q_mfma (forward)");
 }
 extern "C" int ctdd_hollow_attention_bwd_bf16(const void* args_, void* stream) {
@@ -841,9 +882,9 @@ extern "C" int ctdd_hollow_attention_bwd_bf16(const void* args_, void* stream) {
   CTDD_REQUIRE(a.d_out && (a.dq || a.dq_bf16) && (a.dk || a.dk_bf16) && (a.dv || a.dv_bf16), CTDD_EINVAL, "attention bwd: null gradient buffer");
   CTDD_REQUIRE(a.dq_rs % 4 == 0 && a.dk_rs % 4 == 0 && a.dv_rs % 4 == 0 && a.dq_bs % 4 == 0 && a.dk_bs % 4 == 0 && a.dv_bs % 4 == 0, CTDD_EINVAL,
                "attention bwd (matrix cores): gradient rows must be 16-byte aligned");
-  HD_DISPATCH_MFMA((k_hollow_attn_q_mfma<16, true>), (k_hollow_attn_q_mfma<32, true>), (a.Tq + 127) / 128)
+  HD_DISPATCH_MFMA((k_hollow_attn_q_mfma<16, true, ATT_NW>), (k_hollow_attn_q_mfma<32, true, ATT_NW>), (a.Tq + 32 * ATT_NW - 1) / (32 * ATT_NW))
   if (int rc = finish_launch("k_hollow_attn_q_mfma (dQ)")) return rc;
-  HD_DISPATCH_MFMA((k_hollow_attn_kv_mfma<16>), (k_hollow_attn_kv_mfma<32>), (a.Tk + 127) / 128)
+  HD_DISPATCH_MFMA((k_hollow_attn_kv_mfma<16, ATT_NW>), (k_hollow_attn_kv_mfma<32, ATT_NW>), (a.Tk + 32 * ATT_NW - 1) / (32 * ATT_NW))
   return finish_launch("k_hollow_attn_kv_mfma");
 }
 
