@@ -293,6 +293,18 @@ __device__ inline unsigned hk_pack2(float a, float b) {
   v2f v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, v2b));
 }
+template <int MODE>
+__device__ inline void hk_mask_tile(f32x16& s, int Tq, int Tk, int i, bool qok, int jb) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = jb + (r & 3) + 8 * (r >> 2);
+    bool ok = qok & (j < Tk);
+    if (MODE == 0) ok &= j <= i;
+    else if (MODE == 1) ok &= j >= i;
+    else ok &= (j == 0) | ((j <= Tq) & (j - 1 <= i)) | ((j > Tq) & (j - Tq - 1 >= i));
+    s[r] = ok ? s[r] : -INFINITY;
+  }
+}
 template <int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnArgs a) {
   constexpr int KS = HD / 16;                       // k-steps of the score product
@@ -409,16 +421,13 @@ __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnA
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
     } else {
+      // (branch-free, the launch-uniform mode hoisted: a per-register `if` chain on it compiles to scalar lane-mask and / or /
+      //  branch sequences an order of magnitude longer than the softmax arithmetic)
+      if (a.mode == 0) hk_mask_tile<0>(sacc, a.Tq, a.Tk, i, qok, j0 + 4 * kh);
+      else if (a.mode == 1) hk_mask_tile<1>(sacc, a.Tq, a.Tk, i, qok, j0 + 4 * kh);
+      else hk_mask_tile<2>(sacc, a.Tq, a.Tk, i, qok, j0 + 4 * kh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        bool ok = qok && j < a.Tk;
-        if (a.mode == 0) ok = ok && j <= i;
-        else if (a.mode == 1) ok = ok && j >= i;
-        else ok = ok && (j == 0 || (j <= a.Tq ? j - 1 <= i : j - a.Tq - 1 >= i));
-        sacc[r] = ok ? sacc[r] : -INFINITY;
-        mx = fmaxf(mx, sacc[r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
     const float mn = fmaxf(m, mx);
