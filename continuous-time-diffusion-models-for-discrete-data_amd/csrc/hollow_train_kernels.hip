@@ -791,6 +791,40 @@ __global__ __launch_bounds__(256) void k_hollow_relu_bf16(const unsigned short* 
   }
 }
 
+// ============================================================================ column sums (bias gradients), two stages, no atomics
+// partial[blk % nrep][n] (+)= sum over the workgroup's run of rows of x[row][n]; ctdd_unet_sum_batch adds the nrep partials.  A thread keeps
+// eight consecutive columns (one 16-byte load of bf16, two of fp32) of every (256 / (N / 8))-th row of the run.
+__global__ __launch_bounds__(256) void k_hollow_colsum(const float* __restrict__ f, const unsigned short* __restrict__ h, int64_t rows,
+                                                      int N, int ld, float* __restrict__ partial, int nrep) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];                  // [rpi][N]
+  const int tpr = N / 8, rpi = 256 / tpr;                                      // threads per row, rows per iteration
+  const int c8 = (threadIdx.x % tpr) * 8, rl = threadIdx.x / tpr;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(lo + per, rows);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < rpi) {
+    for (int64_t r = lo + rl; r < hi; r += rpi) {
+      if (h) {
+        const uint4 v = *(const uint4*)(h + (size_t)r * ld + c8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[2 * k] += __uint_as_float(w[k] << 16); acc[2 * k + 1] += __uint_as_float(w[k] & 0xFFFF0000u); }
+      } else {
+        const float4 v0 = *(const float4*)(f + (size_t)r * ld + c8), v1 = *(const float4*)(f + (size_t)r * ld + c8 + 4);
+        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w; acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[rl * N + c8 + k] = acc[k];
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float t = 0.0f;
+    for (int q = 0; q < rpi; ++q) t += sm[q * N + n];
+    if (nrep >= (int)gridDim.x) partial[(size_t)blockIdx.x * N + n] = t;
+    else atomicAdd(partial + (size_t)(blockIdx.x % nrep) * N + n, t);          // few workgroups per address: no serialisation to speak of
+  }
+}
+
 // ============================================================================ embedding backward (hollow_networks.py:729-753)
 // x_embed[b][d] = w_in xn[b][d] + b_in feeds l2r[b][d+1] and r2l[b][d-1]:  dxe[b][d] = dl2r[b][d+1] (d <= D-2) + dr2l[b][d-1] (d >= 1)
 // dw_in[e] = sum dxe xn ; db_in[e] = sum dxe
@@ -897,6 +931,16 @@ extern "C" int ctdd_hollow_act(const float* pre, const float* dout, float* out, 
   hipLaunchKernelGGL(k_hollow_act, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pre, dout, out, (unsigned short*)out_bf16, n / 4, act,
                      drop_p, rng, layer);
   return finish_launch("k_hollow_act");
+}
+
+extern "C" int ctdd_hollow_colsum(const float* x_f32, const void* x_bf16, int64_t rows, int N, int ld, float* partial, int nblk, int nrep,
+                                  void* stream) {
+  CTDD_REQUIRE((x_f32 || x_bf16) && partial && rows > 0 && nblk > 0 && nrep > 0 && N >= 8 && N % 8 == 0 && N <= 2048 && ld % 8 == 0 && N <= ld, CTDD_EINVAL,
+               "colsum: rows=%lld N=%d ld=%d nblk=%d", (long long)rows, N, ld, nblk);
+  const int rpi = 256 / (N / 8);
+  const size_t lds = (size_t)rpi * N * sizeof(float);                          // <= 8 KiB
+  hipLaunchKernelGGL(k_hollow_colsum, dim3(nblk), dim3(256), lds, (hipStream_t)stream, x_f32, (const unsigned short*)x_bf16, rows, N, ld, partial, nrep);
+  return finish_launch("k_hollow_colsum");
 }
 
 extern "C" int ctdd_hollow_relu_bf16(const void* src, const void* mask_u, void* out, int64_t n, float drop_p, const uint64_t* rng,

@@ -61,7 +61,8 @@ def lib():
                            ("ctdd_hollow_attention_bwd", [_P, _P]), ("ctdd_hollow_attention_train_bf16", [_P, _P]),
                            ("ctdd_hollow_attention_bwd_bf16", [_P, _P]),
                            ("ctdd_hollow_act", [_P, _P, _P, _P, _I64, _I, _F, _P, _U64, _P]), ("ctdd_hollow_embed_bwd", [_P, _P]),
-                           ("ctdd_hollow_relu_bf16", [_P, _P, _P, _I64, _F, _P, _U64, _P])):
+                           ("ctdd_hollow_relu_bf16", [_P, _P, _P, _I64, _F, _P, _U64, _P]),
+                           ("ctdd_hollow_colsum", [_P, _P, _I64, _I, _I, _P, _I, _I, _P])):
             fn = getattr(l, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -177,26 +178,43 @@ def _wgrad_geometry(rows, N, K, bf16, budget=144 * 1024):
     raise native.CtddError("weight gradient: no chunk fits the kernel's staging slots")
 
 
-def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias, bufs=None):
-    """dW[N][K] = dY^T X (tokens are the contraction index) and, with `bias`, db[N] = column sums of dY as one more entry
-    of the same table launch (a weight gradient against an all-ones input of eight columns).  bufs: zeroed (dW, [N][8])."""
+WGRAD_WORKGROUPS = 512          # M-split target per launch (two per CU: measured best over 256 / 512 / 768 / 1536 at 28800 rows)
+
+
+COLSUM_REPLICAS = 16
+
+
+def _colsum(dy_op, rows, N, ld, bf16, rep=None):
+    """db[N] = column sums of dY: 512 workgroups over the rows into COLSUM_REPLICAS partial rows, then their sum.
+    rep: zeroed (COLSUM_REPLICAS, N rounded up to 8) scratch."""
     dev = dy_op.device
-    if bufs is None:
-        bufs = _zeros(dev, (N, K), (N, 8)) if bias else (_zeros(dev, (N, K))[0], None)
-    dw, dbs = bufs
-    ents = []
-    for xs, gw, Kc in ((x_op, dw, K),) + (((_ones(rows, bf16, dev), dbs, 8),) if bias else ()):
-        a = unet_train._WgradArgs()
-        a.x, a.dy, a.gw = xs.data_ptr(), dy_op.data_ptr(), gw.data_ptr()
-        a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind = 1, rows, 1, rows, 1, N, ld, Kc, Kc, 0, unet_train.WG_1x1
-        a.nwn, a.nlr = _wgrad_geometry(rows, N, Kc, bf16)
-        a.nchunks = -(-rows // a.nlr)
-        groups = -(-N // (32 * a.nwn)) * -(-Kc // (32 * (4 // a.nwn)))
-        a.grid_x, a.tap = max(1, min(a.nchunks, -(-768 // groups))), 0
-        ents.append(a)
-    tab = (unet_train._WgradArgs * len(ents))(*ents)
-    _ck(lib().ctdd_unet_wgrad(_device_table(bytes(tab), dev).data_ptr(), C.addressof(tab), len(ents), 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
-    return dw, (dbs[:, 0] if bias else None)
+    n8 = -(-N // 8) * 8
+    nblk = int(max(1, min(512, rows // 32)))
+    if rep is None:
+        rep = torch.zeros((COLSUM_REPLICAS, n8), dtype=torch.float32, device=dev)
+    out = torch.empty((n8,), dtype=torch.float32, device=dev)
+    _ck(lib().ctdd_hollow_colsum(None if bf16 else dy_op.data_ptr(), dy_op.data_ptr() if bf16 else None, rows, n8, ld, rep.data_ptr(), nblk,
+                                 rep.shape[0], _st()), "ctdd_hollow_colsum")
+    _ck(lib().ctdd_unet_sum_batch(rep.data_ptr(), rep.shape[0], n8, 1, n8, out.data_ptr(), 0, _st()), "ctdd_unet_sum_batch")
+    return out[:N]
+
+
+def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias, bufs=None):
+    """dW[N][K] = dY^T X (tokens are the contraction index: ctdd_unet_wgrad, kind 1x1) and, with `bias`, db[N] = the column
+    sums of dY (_colsum; a second table entry against an all-ones input cost 12-30 us per launch: re-read of dY + its own M-split
+    atomics; the two-stage column sum reads dY once).  bufs: zeroed (dW, column-sum replicas (COLSUM_REPLICAS, N)) scratch."""
+    dev = dy_op.device
+    dw = bufs[0] if bufs is not None else torch.zeros((N, K), dtype=torch.float32, device=dev)
+    a = unet_train._WgradArgs()
+    a.x, a.dy, a.gw = x_op.data_ptr(), dy_op.data_ptr(), dw.data_ptr()
+    a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff, a.kind = 1, rows, 1, rows, 1, N, ld, K, K, 0, unet_train.WG_1x1
+    a.nwn, a.nlr = _wgrad_geometry(rows, N, K, bf16)
+    a.nchunks = -(-rows // a.nlr)
+    groups = -(-N // (32 * a.nwn)) * -(-K // (32 * (4 // a.nwn)))
+    a.grid_x, a.tap = max(1, min(a.nchunks, -(-WGRAD_WORKGROUPS // groups))), 0
+    tab = (unet_train._WgradArgs * 1)(a)
+    _ck(lib().ctdd_unet_wgrad(_device_table(bytes(tab), dev).data_ptr(), C.addressof(tab), 1, 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
+    return dw, (_colsum(dy_op, rows, N, ld, bf16, None if bufs is None else bufs[1]) if bias else None)
 
 
 def _layernorm(x, y, gamma, beta, film, eps, want_f32=True, want_hi=False):
@@ -448,7 +466,7 @@ class AttnBlockFn(torch.autograd.Function):
         B, D, H, hd, mode, p_att, p_drop, l_att, l_drop, bf16, eps, pk_in, pk_out = ctx.meta
         E, R = H * hd, B * D
         dout = dout.contiguous()
-        zw_out, zb_out, zw_in, zb_in, rep = _zeros(dout.device, (E, E), (E, 8), (3 * E, E), (3 * E, 8), (LN_REPLICAS, 2 * E))
+        zw_out, zb_out, zw_in, zb_in, rep = _zeros(dout.device, (E, E), (COLSUM_REPLICAS, E), (3 * E, E), (COLSUM_REPLICAS, 3 * E), (LN_REPLICAS, 2 * E))
         do = _dropout_(dout.clone(), p_drop, rng, l_drop) if p_drop > 0.0 else dout
         datt, dw_out, db_out = _linear_bwd(att_op, w_out, do.view(R, E), R, bf16, True, wt=pk_out[1], bufs=(zw_out, zb_out))
         (dqkv, _, _), hi = _attention_bwd(qkv, None, None, att, stats, datt, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16,
@@ -498,7 +516,7 @@ class MlpBlockFn(torch.autograd.Function):
         B, D, E, p_drop, l1, l2, bf16, eps, pk1, pk2 = ctx.meta
         R, M = B * D, w1.shape[0]
         dout = dout.contiguous()
-        zw2, zw1, zb1, rep = _zeros(dout.device, (E, M), (M, E), (M, 8), (LN_REPLICAS, 2 * E))
+        zw2, zw1, zb1, rep = _zeros(dout.device, (E, M), (M, E), (COLSUM_REPLICAS, M), (LN_REPLICAS, 2 * E))
         do = _dropout_(dout.clone(), p_drop, rng, l2) if p_drop > 0.0 else dout
         if bf16:
             do_hi = _cast(do.view(R, E), R, E, E, True)

@@ -48,6 +48,12 @@ int ctdd_hollow_attention_bwd_bf16(const void* attn_train_args, void* stream);
 int ctdd_hollow_act(const float* pre, const float* dout, float* out, void* out_bf16, int64_t n, int act, float drop_p,
                     const uint64_t* rng, uint64_t layer, void* stream);
 
+/* column sums of a (rows, N) matrix (bias gradients), first stage: partial[blk % nrep][n] (+)= the sum over workgroup blk's run
+ * of rows (nblk workgroups; N % 8 == 0, N <= 2048); nrep < nblk: `partial` (nrep, N) must be zeroed, nblk / nrep workgroups
+ * meet per address in float atomics; the caller adds the nrep partials (ctdd_unet_sum_batch). */
+int ctdd_hollow_colsum(const float* x_f32, const void* x_bf16, int64_t rows, int N, int ld, float* partial, int nblk, int nrep,
+                       void* stream);
+
 /* bf16-only ReLU (+ dropout) of the MLP hidden tensor (bf16 mode), n % 8 == 0:
  * mask_u == NULL: out = dropout(relu(src))  (Philox masks as ctdd_hollow_act on the same element indices; in place allowed);
  * mask_u != NULL: out = src * [mask_u != 0] / (1 - p)  -- the backward, with the saved forward output as the mask. */
