@@ -252,7 +252,7 @@ class TrainCtx:
             cost.append(a.nchunks * ((KP // 16) * (9 if a.kind == WG_3x3 else 1) + int(getattr(eng.cfg.model, "wgrad_chunk_overhead", 48))))
             groups.append(-(-a.N // (32 * a.nwn)) * -(-a.C // (32 * nwc)))
         total = sum(c * g for c, g in zip(cost, groups))
-        target = max(1, total // (256 * int(getattr(eng.cfg.model, "wgrad_wgs_per_cu", 3))))
+        target = max(1, total // (256 * int(getattr(eng.cfg.model, "wgrad_wgs_per_cu", 2))))
         flops = 0
         for a, c in zip(ents, cost):
             a.grid_x = max(1, min(a.nchunks, -(-c // target)))
