@@ -54,6 +54,7 @@ struct LnBwdArgs {
   float* dgamma; float* dbeta;                              // [E], atomically accumulated
   float* dfilm;                                             // [B][2E] (da | db), atomically accumulated, or null
   int nrep; int rep_stride;                                 // > 1: workgroup w adds into dgamma / dbeta + (w % nrep) * rep_stride (the caller sums the replicas)
+  const float* dres; int64_t dres_bs;                       // optional: dx = dres + gradient (the residual stream's incoming gradient; out of place)
 };
 // KN = ceil(E / 64) columns per lane; RG rows in flight per wave (independent loads and reduction chains overlap); the
 // four waves of a workgroup meet in LDS before ONE atomic per column and workgroup (thousands of waves on the same
@@ -131,12 +132,13 @@ __global__ __launch_bounds__(256) void k_hollow_ln_bwd(const LnBwdArgs a) {
       const int j = jb + r;
       float* dx = a.dx + (size_t)b * a.dx_bs + (size_t)j * E;
       float* dy = (a.dy && a.y) ? a.dy + (size_t)b * a.dy_bs + (size_t)j * E : nullptr;
+      const float* dres = a.dres ? a.dres + (size_t)b * a.dres_bs + (size_t)j * E : nullptr;
 #pragma unroll
       for (int k = 0; k < KN; ++k) {
         const int e = lane + 64 * k;
         if (e < E) {
           const float v = q[r] * (d[r][k] - m1[r] - h[r][k] * m2[r]);
-          dx[e] = a.acc_dx ? dx[e] + v : v;
+          dx[e] = dres ? dres[e] + v : (a.acc_dx ? dx[e] + v : v);
           if (dy) dy[e] = a.acc_dy ? dy[e] + v : v;
         }
       }
@@ -791,6 +793,27 @@ __global__ __launch_bounds__(256) void k_hollow_relu_bf16(const unsigned short* 
   }
 }
 
+// out = dropout(x) (+ res), to fp32 and / or bf16 (p = 0: a plain add / cast).  One pass where the block Functions ran a clone, an
+// in-place dropout, an add or a cast; masks Philox(seed, step * 4096 + layer, quad) as k_hollow_act.
+__global__ __launch_bounds__(256) void k_hollow_dropout(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                                       unsigned short* __restrict__ out_bf16, int64_t nquad, float drop_p,
+                                                       const uint64_t* rng, uint64_t layer) {
+  const float inv_keep = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint64_t seed = drop_p > 0.0f ? rng[0] : 0, ctr = drop_p > 0.0f ? rng[1] * 4096u + layer : 0;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nquad; v += (int64_t)gridDim.x * 256) {
+    const float4 x4 = *(const float4*)(x + v * 4);
+    float r[4] = {x4.x, x4.y, x4.z, x4.w};
+    if (drop_p > 0.0f) {
+      const unsigned keep = keep4v(seed, ctr, (uint64_t)v, drop_p);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = (keep >> k) & 1u ? r[k] * inv_keep : 0.0f;
+    }
+    if (res) { const float4 q4 = *(const float4*)(res + v * 4); r[0] += q4.x; r[1] += q4.y; r[2] += q4.z; r[3] += q4.w; }
+    if (out) *(float4*)(out + v * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    if (out_bf16) *(uint2*)(out_bf16 + v * 4) = make_uint2(ht_pack2(r[0], r[1]), ht_pack2(r[2], r[3]));
+  }
+}
+
 // ============================================================================ column sums (bias gradients), two stages, no atomics
 // partial[blk % nrep][n] (+)= sum over the workgroup's run of rows of x[row][n]; ctdd_unet_sum_batch adds the nrep partials.  A thread keeps
 // eight consecutive columns (one 16-byte load of bf16, two of fp32) of every (256 / (N / 8))-th row of the run.
@@ -941,6 +964,17 @@ extern "C" int ctdd_hollow_colsum(const float* x_f32, const void* x_bf16, int64_
   const size_t lds = (size_t)rpi * N * sizeof(float);                          // <= 8 KiB
   hipLaunchKernelGGL(k_hollow_colsum, dim3(nblk), dim3(256), lds, (hipStream_t)stream, x_f32, (const unsigned short*)x_bf16, rows, N, ld, partial, nrep);
   return finish_launch("k_hollow_colsum");
+}
+
+extern "C" int ctdd_hollow_dropout(const float* x, const float* res, float* out, void* out_bf16, int64_t n, float drop_p, const uint64_t* rng,
+                                   uint64_t layer, void* stream) {
+  CTDD_REQUIRE(x && (out || out_bf16) && n > 0 && n % 4 == 0, CTDD_EINVAL, "dropout: n=%lld", (long long)n);
+  CTDD_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f && (drop_p == 0.0f || rng), CTDD_EINVAL, "dropout: rate %g", (double)drop_p);
+  int64_t g = (n / 4 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_hollow_dropout, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, res, out, (unsigned short*)out_bf16, n / 4, drop_p,
+                     rng, layer);
+  return finish_launch("k_hollow_dropout");
 }
 
 extern "C" int ctdd_hollow_relu_bf16(const void* src, const void* mask_u, void* out, int64_t n, float drop_p, const uint64_t* rng,

@@ -34,7 +34,7 @@ class _LnBwdArgs(C.Structure):
     _fields_ = [("x", _P), ("y", _P), ("x_bs", _I64), ("y_bs", _I64), ("gamma", _P), ("beta", _P), ("eps", _F), ("film", _P),
                 ("film_stride", _I), ("dout", _P), ("dout_bs", _I64), ("B", _I), ("T", _I), ("E", _I), ("rpw", _I), ("dx", _P),
                 ("dx_bs", _I64), ("acc_dx", _I), ("dy", _P), ("dy_bs", _I64), ("acc_dy", _I), ("dgamma", _P), ("dbeta", _P), ("dfilm", _P),
-                ("nrep", _I), ("rep_stride", _I)]
+                ("nrep", _I), ("rep_stride", _I), ("dres", _P), ("dres_bs", _I64)]
 
 
 class _AttnTrainArgs(C.Structure):
@@ -62,7 +62,8 @@ def lib():
                            ("ctdd_hollow_attention_bwd_bf16", [_P, _P]),
                            ("ctdd_hollow_act", [_P, _P, _P, _P, _I64, _I, _F, _P, _U64, _P]), ("ctdd_hollow_embed_bwd", [_P, _P]),
                            ("ctdd_hollow_relu_bf16", [_P, _P, _P, _I64, _F, _P, _U64, _P]),
-                           ("ctdd_hollow_colsum", [_P, _P, _I64, _I, _I, _P, _I, _I, _P])):
+                           ("ctdd_hollow_colsum", [_P, _P, _I64, _I, _I, _P, _I, _I, _P]),
+                           ("ctdd_hollow_dropout", [_P, _P, _P, _P, _I64, _F, _P, _U64, _P])):
             fn = getattr(l, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -244,13 +245,11 @@ def _zeros(dev, *shapes):
     return out
 
 
-def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dx=None, rep=None):
-    """-> (dx, dgamma, dbeta, dfilm); with `dx` given the gradient is ADDED into it (the residual stream's gradient).
+def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dres=None, rep=None):
+    """-> (dx, dgamma, dbeta, dfilm); dres: dx = dres + gradient (the residual stream's incoming gradient, out of place).
     rep: zeroed (LN_REPLICAS, 2E) scratch for the replicated dgamma | dbeta accumulators."""
     B, T, E = x.shape
-    acc = dx is not None
-    if dx is None:
-        dx = torch.empty_like(x)
+    dx = torch.empty_like(x)
     if rep is None:
         rep = torch.zeros((LN_REPLICAS, 2 * E), dtype=torch.float32, device=x.device)
     dfilm = None if film is None else torch.zeros_like(film)
@@ -259,9 +258,10 @@ def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dx=None, rep=None):
     a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
     a.film, a.film_stride = _p(film), 0 if film is None else film.shape[1]
     a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 4
-    a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, int(acc)
+    a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, 0
     a.dgamma, a.dbeta, a.dfilm = rep.data_ptr(), rep.data_ptr() + 4 * E, _p(dfilm)
     a.nrep, a.rep_stride = rep.shape[0], 2 * E
+    a.dres, a.dres_bs = _p(dres), T * E
     _ck(lib().ctdd_hollow_layernorm_bwd(C.byref(a), _st()), "ctdd_hollow_layernorm_bwd")
     gb = torch.empty((2 * E,), dtype=torch.float32, device=x.device)
     _ck(lib().ctdd_unet_sum_batch(rep.data_ptr(), rep.shape[0], 2 * E, 1, 2 * E, gb.data_ptr(), 0, _st()), "ctdd_unet_sum_batch")
@@ -341,9 +341,13 @@ def _act(pre, dout, act, drop_p, rng, layer, want_f32=True, want_hi=False):
     return out, out_hi
 
 
-def _dropout_(x, p, rng, layer):
-    _ck(lib().ctdd_unet_dropout(x.data_ptr(), None, x.numel(), float(p), rng.data_ptr(), int(layer), _st()), "ctdd_unet_dropout")
-    return x
+def _dropout(x, p, rng, layer, res=None, want_f32=True, want_hi=False):
+    """dropout(x) (+ res) -> (fp32 or None, bf16 or None) in one pass (p = 0: an add / a cast)."""
+    out = torch.empty_like(x) if want_f32 else None
+    out_hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_hi else None
+    _ck(lib().ctdd_hollow_dropout(x.data_ptr(), _p(res), _p(out), _p(out_hi), x.numel(), float(p), _p(rng) if p > 0 else None, int(layer), _st()),
+        "ctdd_hollow_dropout")
+    return out, out_hi
 
 
 def _add(p, q):
@@ -453,7 +457,7 @@ class AttnBlockFn(torch.autograd.Function):
         att_op = att_hi if bf16 else att
         if p_drop > 0.0:
             o, _ = _gemm(att_op, pk_out[0], b_out.detach(), None, R, E, E, bf16)
-            out = _add(_dropout_(o, p_drop, rng, l_drop), h.view(R, E))
+            out, _ = _dropout(o, p_drop, rng, l_drop, res=h.view(R, E))
         else:
             out, _ = _gemm(att_op, pk_out[0], b_out.detach(), h.view(R, E), R, E, E, bf16)
         ctx.save_for_backward(h, ln_w, ln_b, w_in, w_out, z_op, qkv, att, att_op, stats, rng)
@@ -467,12 +471,15 @@ class AttnBlockFn(torch.autograd.Function):
         E, R = H * hd, B * D
         dout = dout.contiguous()
         zw_out, zb_out, zw_in, zb_in, rep = _zeros(dout.device, (E, E), (COLSUM_REPLICAS, E), (3 * E, E), (COLSUM_REPLICAS, 3 * E), (LN_REPLICAS, 2 * E))
-        do = _dropout_(dout.clone(), p_drop, rng, l_drop) if p_drop > 0.0 else dout
-        datt, dw_out, db_out = _linear_bwd(att_op, w_out, do.view(R, E), R, bf16, True, wt=pk_out[1], bufs=(zw_out, zb_out))
+        if bf16:                                             # dropout mask and bf16 operand copy in one pass over dout
+            do, do_hi = None, _dropout(dout.view(R, E), p_drop, rng, l_drop, want_f32=False, want_hi=True)[1]
+        else:
+            do, do_hi = (_dropout(dout.view(R, E), p_drop, rng, l_drop)[0] if p_drop > 0.0 else dout.view(R, E)), None
+        datt, dw_out, db_out = _linear_bwd(att_op, w_out, do, R, bf16, True, dy_hi=do_hi, wt=pk_out[1], bufs=(zw_out, zb_out))
         (dqkv, _, _), hi = _attention_bwd(qkv, None, None, att, stats, datt, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16,
                                           want_f32=False)
         dz, dw_in, db_in = _linear_bwd(z_op, w_in, dqkv, R, bf16, True, dy_hi=hi[0], wt=pk_in[1], bufs=(zw_in, zb_in))
-        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone(), rep=rep)
+        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dres=dout, rep=rep)
         return dh, dg, dbeta, dw_in, db_in, dw_out, db_out, None, None
 
 
@@ -503,7 +510,7 @@ class MlpBlockFn(torch.autograd.Function):
             u_op = pre
         if p_drop > 0.0:
             o, _ = _gemm(u_op, pk2[0], None, None, R, M, E, bf16)
-            out = _add(_dropout_(o, p_drop, rng, l2), h.view(R, E))
+            out, _ = _dropout(o, p_drop, rng, l2, res=h.view(R, E))
         else:
             out, _ = _gemm(u_op, pk2[0], None, h.view(R, E), R, M, E, bf16)
         ctx.save_for_backward(h, ln_w, ln_b, w1, w2, z_op, pre, u_op, rng)
@@ -517,19 +524,19 @@ class MlpBlockFn(torch.autograd.Function):
         R, M = B * D, w1.shape[0]
         dout = dout.contiguous()
         zw2, zw1, zb1, rep = _zeros(dout.device, (E, M), (M, E), (COLSUM_REPLICAS, M), (LN_REPLICAS, 2 * E))
-        do = _dropout_(dout.clone(), p_drop, rng, l2) if p_drop > 0.0 else dout
         if bf16:
-            do_hi = _cast(do.view(R, E), R, E, E, True)
+            do_hi = _dropout(dout.view(R, E), p_drop, rng, l2, want_f32=False, want_hi=True)[1]
             dw2, _ = _wgrad(u_op, do_hi, R, E, E, M, True, False, (zw2, None))
             _, du_hi = _gemm(do_hi, pk2[1], None, None, R, E, M, True, want_hi=True, want_f32=False)
             _ck(lib().ctdd_hollow_relu_bf16(du_hi.data_ptr(), u_op.data_ptr(), du_hi.data_ptr(), du_hi.numel(), float(p_drop), None, 0, _st()),
                 "ctdd_hollow_relu_bf16")
             dz, dw1, db1 = _linear_bwd(z_op, w1, None, R, True, True, dy_hi=du_hi, wt=pk1[1], bufs=(zw1, zb1))
         else:
-            du, dw2, _ = _linear_bwd(u_op, w2, do.view(R, E), R, False, False, wt=pk2[1], bufs=(zw2, None))
+            do = _dropout(dout.view(R, E), p_drop, rng, l2)[0] if p_drop > 0.0 else dout.view(R, E)
+            du, dw2, _ = _linear_bwd(u_op, w2, do, R, False, False, wt=pk2[1], bufs=(zw2, None))
             dpre, _ = _act(pre, du, 1, p_drop, rng if p_drop > 0 else None, l1)
             dz, dw1, db1 = _linear_bwd(z_op, w1, dpre, R, False, True, wt=pk1[1], bufs=(zw1, zb1))
-        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dx=dout.clone(), rep=rep)
+        dh, dg, dbeta, _ = _layernorm_bwd(h, None, ln_w, ln_b, None, eps, dz.view(B, D, E), dres=dout, rep=rep)
         return dh, dg, dbeta, dw1, db1, dw2, None, None
 
 
@@ -556,12 +563,12 @@ class DropoutFn(torch.autograd.Function):
     def forward(ctx, x, drop_p, rng, layer):
         ctx.save_for_backward(rng)
         ctx.meta = (float(drop_p), int(layer))
-        return _dropout_(x.clone(), drop_p, rng, layer)
+        return _dropout(x.contiguous(), drop_p, rng, layer)[0]
 
     @staticmethod
     def backward(ctx, dy):
         (rng,) = ctx.saved_tensors
-        return _dropout_(dy.clone(), ctx.meta[0], rng, ctx.meta[1]), None, None, None
+        return _dropout(dy.contiguous(), ctx.meta[0], rng, ctx.meta[1])[0], None, None, None
 
 
 class AddFn(torch.autograd.Function):

@@ -70,7 +70,7 @@ UNET_TRAIN_EXPORTS = ("ctdd_unet_wgrad", "ctdd_unet_gn_bwd", "ctdd_unet_dropout"
                       "ctdd_unet_downsum2x", "ctdd_unet_upsample2x_f32", "ctdd_unet_cast_rows", "ctdd_unet_attention_bwd",
                       "ctdd_unet_first_conv_wgrad", "ctdd_unet_first_conv_wgrad_scratch", "ctdd_unet_pack_weights",
                       "ctdd_unet_unpack_grads")    # bound in ctdd/unet_train.py
-HOLLOW_TRAIN_EXPORTS = ("ctdd_hollow_layernorm_bwd", "ctdd_hollow_attention_train", "ctdd_hollow_attention_bwd", "ctdd_hollow_attention_train_bf16", "ctdd_hollow_attention_bwd_bf16", "ctdd_hollow_act", "ctdd_hollow_relu_bf16", "ctdd_hollow_colsum",
+HOLLOW_TRAIN_EXPORTS = ("ctdd_hollow_layernorm_bwd", "ctdd_hollow_attention_train", "ctdd_hollow_attention_bwd", "ctdd_hollow_attention_train_bf16", "ctdd_hollow_attention_bwd_bf16", "ctdd_hollow_act", "ctdd_hollow_relu_bf16", "ctdd_hollow_colsum", "ctdd_hollow_dropout",
                         "ctdd_hollow_embed_bwd")                                       # bound in ctdd/hollow_train.py
 EXPORTS = tuple(_SIGS) + UNET_EXPORTS + HOLLOW_EXPORTS + UNET_TRAIN_EXPORTS + HOLLOW_TRAIN_EXPORTS
 

@@ -23,6 +23,7 @@ typedef struct {
   float* dx; int64_t dx_bs; int acc_dx; float* dy; int64_t dy_bs; int acc_dy; float* dgamma; float* dbeta; float* dfilm;
   int nrep, rep_stride;   /* nrep > 1: workgroup w accumulates into dgamma / dbeta + (w % nrep) * rep_stride; the caller sums the replicas
                              (thousands of workgroups on the same 2E addresses serialise in L2) */
+  const float* dres; int64_t dres_bs;   /* optional: dx = dres + gradient, out of place (the residual stream's incoming gradient) */
 } ctdd_hollow_ln_bwd_args;
 int ctdd_hollow_layernorm_bwd(const void* ln_bwd_args, void* stream);
 
@@ -47,6 +48,10 @@ int ctdd_hollow_attention_bwd_bf16(const void* attn_train_args, void* stream);
  * act 0 identity, 1 ReLU, 2 GELU (erf); n % 4 == 0 */
 int ctdd_hollow_act(const float* pre, const float* dout, float* out, void* out_bf16, int64_t n, int act, float drop_p,
                     const uint64_t* rng, uint64_t layer, void* stream);
+
+/* out = dropout(x) (+ res) as fp32 and / or bf16 (n % 4 == 0; p = 0: add / cast only); masks as ctdd_hollow_act's */
+int ctdd_hollow_dropout(const float* x, const float* res, float* out, void* out_bf16, int64_t n, float drop_p, const uint64_t* rng,
+                        uint64_t layer, void* stream);
 
 /* column sums of a (rows, N) matrix (bias gradients), first stage: partial[blk % nrep][n] (+)= the sum over workgroup blk's run
  * of rows (nblk workgroups; N % 8 == 0, N <= 2048); nrep < nblk: `partial` (nrep, N) must be zeroed, nblk / nrep workgroups
