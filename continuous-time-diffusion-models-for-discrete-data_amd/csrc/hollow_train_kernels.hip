@@ -184,11 +184,22 @@ __device__ inline bool attn_allowed(int mode, int Tq, int i, int j) {
   if (mode == 1) return j >= i;
   return j == 0 || (j <= Tq ? j - 1 <= i : j - Tq - 1 >= i);
 }
-// keep flag of probability (b, h, i, j): one Philox block per four consecutive keys
+// Dropout on the attention probabilities: one Philox block per (query, EIGHT consecutive keys), its 128 bits as eight 16-bit
+// uniforms (Philox4x32-10 is 20 quarter-rate 32 x 32 -> 64 multiplies: at one block per four probabilities it was ~45 % of the
+// matrix-core kernels' instructions).  keep_k = u16_k >= thr, thr = round(p 65536): the rate in force is thr / 65536 (|error| <
+// 8e-6), and 1 / (1 - thr / 65536) is the rescale every kernel uses.
+__device__ inline unsigned attn_thr(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
+__device__ inline float attn_inv_keep(float p) { return p > 0.0f ? 1.0f / (1.0f - (float)attn_thr(p) * (1.0f / 65536.0f)) : 1.0f; }
+__device__ inline unsigned keep8v(uint64_t seed, uint64_t ctr, uint64_t oct, unsigned thr) {
+  const u4 r = philox_row(seed, ctr, oct, 0x4154544Eu);
+  return ((r.x & 0xFFFFu) >= thr ? 1u : 0u) | ((r.x >> 16) >= thr ? 2u : 0u) | ((r.y & 0xFFFFu) >= thr ? 4u : 0u) | ((r.y >> 16) >= thr ? 8u : 0u) |
+         ((r.z & 0xFFFFu) >= thr ? 16u : 0u) | ((r.z >> 16) >= thr ? 32u : 0u) | ((r.w & 0xFFFFu) >= thr ? 64u : 0u) | ((r.w >> 16) >= thr ? 128u : 0u);
+}
+// keep flag of probability (b, h, i, j)  (the fp32 kernels: one block per probability -- their mode is the parity mode)
 __device__ inline bool attn_keep(const AttnTrainArgs& a, int b, int h, int i, int j) {
-  const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
-  const uint64_t quad = (((uint64_t)b * a.H + h) * a.Tq + i) * quads + (uint64_t)(j >> 2);
-  return (keep4(a.rng, a.layer, quad, a.drop_p) >> (j & 3)) & 1u;
+  const uint64_t octs = (uint64_t)(a.Tk + 7) / 8;
+  const uint64_t oct = (((uint64_t)b * a.H + h) * a.Tq + i) * octs + (uint64_t)(j >> 3);
+  return (keep8v(a.rng[0], a.rng[1] * 4096u + a.layer, oct, attn_thr(a.drop_p)) >> (j & 7)) & 1u;
 }
 constexpr int TQ = 128, TK = 32;
 template <int HD>
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(TQ) void k_hollow_attn_train(const AttnTrainArgs a)
     for (int c = 0; c < HD; ++c) qv[c] = qr[c] * a.scale;
   }
   float m = -INFINITY, l = 0.0f;
-  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float inv_keep = attn_inv_keep(a.drop_p);
   for (int j0 = 0; j0 < a.Tk; j0 += TK) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < TK * HD; idx += TQ) {
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(TQ) void k_hollow_attn_bwd_q(const AttnTrainArgs a)
     m = st[0]; il = 1.0f / st[1];
     st[2] = Di;
   }
-  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float inv_keep = attn_inv_keep(a.drop_p);
   for (int j0 = 0; j0 < a.Tk; j0 += TK) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < TK * HD; idx += TQ) {
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(TQ) void k_hollow_attn_bwd_kv(const AttnTrainArgs a
 #pragma unroll
     for (int c = 0; c < HD; ++c) { kv[c] = kr[c]; vv[c] = vr[c]; }
   }
-  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float inv_keep = attn_inv_keep(a.drop_p);
   for (int i0 = 0; i0 < a.Tq; i0 += TK) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < TK * HD; idx += TQ) {
@@ -493,9 +504,10 @@ __global__ __launch_bounds__(64 * NW) void k_hollow_attn_q_mfma(const AttnTrainA
     Di += __shfl_xor(Di, 32, WAVE);
     if (qok && kh == 0) st[2] = Di;
   }
-  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-  const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
-  const uint64_t qrow = (((uint64_t)b * a.H + h) * a.Tq + (qok ? i : 0)) * quads;
+  const float inv_keep = attn_inv_keep(a.drop_p);
+  const uint64_t octs = (uint64_t)(a.Tk + 7) / 8;
+  const uint64_t qrow = (((uint64_t)b * a.H + h) * a.Tq + (qok ? i : 0)) * octs;
+  const unsigned thr = attn_thr(a.drop_p);
   const uint64_t rseed = a.drop_p > 0.0f ? a.rng[0] : 0, rctr = a.drop_p > 0.0f ? a.rng[1] * 4096u + a.layer : 0;   // (once: not per chunk)
   f32x16t oacc;
 #pragma unroll
@@ -539,9 +551,14 @@ __global__ __launch_bounds__(64 * NW) void k_hollow_attn_q_mfma(const AttnTrainA
     }
     unsigned keep = 0xFFFFu;                                                     // bit r: probability r survives the dropout
     if (a.drop_p > 0.0f) {
+      // registers 4 g .. 4 g + 3 are keys 8 g + 4 kh + 0..3 of the chunk: bits 4 kh .. 4 kh + 3 of octet g.  The two lanes of a
+      // query split the four octets (half kh draws octets 2 kh, 2 kh + 1) and exchange them
+      const unsigned mine = keep8v(rseed, rctr, qrow + (uint64_t)(j0 >> 3) + 2 * kh, thr) | (keep8v(rseed, rctr, qrow + (uint64_t)(j0 >> 3) + 2 * kh + 1, thr) << 8);
+      const unsigned other = (unsigned)__shfl_xor((int)mine, 32, WAVE);
+      const unsigned all = kh ? (other | (mine << 16)) : (mine | (other << 16));   // octet g at bits 8 g
       keep = 0u;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) keep |= keep4v(rseed, rctr, qrow + (uint64_t)((j0 + 8 * g + 4 * kh) >> 2), a.drop_p) << (4 * g);
+      for (int g = 0; g < 4; ++g) keep |= ((all >> (8 * g + 4 * kh)) & 0xFu) << (4 * g);
     }
     unsigned pw[8];
     if (!BWD) {
@@ -609,8 +626,9 @@ __global__ __launch_bounds__(64 * NW) void k_hollow_attn_kv_mfma(const AttnTrain
   bf16x8t kf[KS], vf[KS];
   row_frags<HD>(a.k + (size_t)b * a.k_bs + (size_t)(kok ? j : 0) * a.k_rs + h * HD, kok, 1.0f, kh, kf);
   row_frags<HD>(a.v + (size_t)b * a.v_bs + (size_t)(kok ? j : 0) * a.v_rs + h * HD, kok, 1.0f, kh, vf);
-  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-  const uint64_t quads = (uint64_t)(a.Tk + 3) / 4;
+  const float inv_keep = attn_inv_keep(a.drop_p);
+  const uint64_t octs = (uint64_t)(a.Tk + 7) / 8;
+  const unsigned thr = attn_thr(a.drop_p);
   const uint64_t rseed = a.drop_p > 0.0f ? a.rng[0] : 0, rctr = a.drop_p > 0.0f ? a.rng[1] * 4096u + a.layer : 0;
   f32x16t kacc, vacc;
 #pragma unroll
@@ -671,21 +689,20 @@ __global__ __launch_bounds__(64 * NW) void k_hollow_attn_kv_mfma(const AttnTrain
     }
     unsigned keep = 0xFFFFu;                                                     // bit r: probability (query r, this key) survives
     if (a.drop_p > 0.0f) {
-      // the Philox block of (query, four consecutive keys) serves four neighbouring lanes: lane computes the blocks of the
-      // registers r = 4 g + (col & 3) and the four exchange them
+      // the Philox block of (query, eight consecutive keys) serves eight neighbouring lanes: lane c of them draws the blocks of
+      // the registers 2 c, 2 c + 1 and the eight exchange them
       unsigned mine = 0u;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i = i0 + (col & 3) + 8 * g + 4 * kh;
-        const uint64_t quad = (((uint64_t)b * a.H + h) * a.Tq + (uint64_t)min(i, a.Tq - 1)) * quads + (uint64_t)(min(j, a.Tk - 1) >> 2);
-        mine |= keep4v(rseed, rctr, quad, a.drop_p) << (4 * g);
+      for (int e = 0; e < 2; ++e) {
+        const int r = 2 * (col & 7) + e, i = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const uint64_t oct = (((uint64_t)b * a.H + h) * a.Tq + (uint64_t)min(i, a.Tq - 1)) * octs + (uint64_t)(min(j, a.Tk - 1) >> 3);
+        mine |= keep8v(rseed, rctr, oct, thr) << (8 * e);
       }
       keep = 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned w = (unsigned)__shfl((int)mine, (lane & ~3) | u, WAVE);  // blocks of the registers 4 g + u
-#pragma unroll
-        for (int g = 0; g < 4; ++g) keep |= ((w >> (4 * g + (j & 3))) & 1u) << (4 * g + u);
+      for (int c = 0; c < 8; ++c) {
+        const unsigned w = (unsigned)__shfl((int)mine, (lane & ~7) | c, WAVE);  // blocks of the registers 2 c, 2 c + 1
+        keep |= (((w >> (j & 7)) & 1u) << (2 * c)) | (((w >> (8 + (j & 7))) & 1u) << (2 * c + 1));
       }
     }
     const unsigned okm = a.mode == 0 ? mask_bits_kv<0>(a.Tq, j, kok, i0 + 4 * kh)
