@@ -37,6 +37,11 @@ class _LnArgs(C.Structure):
                 ("film", _P), ("film_stride", _I), ("B", _I), ("T", _I), ("E", _I), ("out", _P), ("out_hi", _P), ("out_hi_bs", _I64), ("out_lo", _P)]
 
 
+class _GemmArgs(C.Structure):
+    _fields_ = [("a", _P * 3), ("nseg", _I), ("w", _P), ("bias", _P), ("res", _P), ("out_f32", _P), ("out_hi", _P), ("out_lo", _P),
+                ("M", _I), ("N", _I), ("K", _I), ("act", _I)]
+
+
 class _AttnArgs(C.Structure):
     _fields_ = [("q", _P), ("k", _P), ("v", _P), ("q_bs", _I64), ("k_bs", _I64), ("v_bs", _I64), ("q_rs", _I), ("k_rs", _I),
                 ("v_rs", _I), ("B", _I), ("Tq", _I), ("Tk", _I), ("H", _I), ("hd", _I), ("mode", _I), ("scale", _F), ("out", _P),
@@ -53,7 +58,7 @@ def _lib():
         for name, argt in (("ctdd_hollow_embed", [_P, _P]), ("ctdd_hollow_layernorm", [_P, _P]),
                            ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _I64, _P]),
                            ("ctdd_hollow_put_rows", [_P, _P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P]),
-                           ("ctdd_hollow_attention_bf16", [_P, _P])):
+                           ("ctdd_hollow_attention_bf16", [_P, _P]), ("ctdd_gemm_bf16", [_P, _P])):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -164,7 +169,19 @@ class HollowEngine:
             else:
                 bk = 32 if K % 32 == 0 else 16
                 bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
-            if use_bf16 and N % 8 == 0 and K % 16 == 0 and getattr(m, "engine_linear", "patch") == "patch":
+            if use_bf16 and N % 8 == 0 and K % 64 == 0 and getattr(m, "engine_linear", "patch") == "gemm":
+                # the plain GEMM kernel of the training path (csrc/gemm_kernels.hip); the hi / lo split product is three A segments
+                # against the concatenated weight.  Opt-in (model.engine_linear = "gemm"): at the inference shapes (K' = 3 K, 5e4 rows) the
+                # tuned slab kernel below measured the same or slightly better (MNIST hollow forward: linears 9.2 vs 9.5 ms)
+                ga = _GemmArgs()
+                ga.nseg, ga.w, ga.bias, ga.res = a.nseg, a.w_hi, a.bias, a.res_f32
+                for si in range(a.nseg):
+                    ga.a[si] = a.seg[si].hi
+                ga.out_f32, ga.out_hi, ga.out_lo, ga.M, ga.N, ga.K, ga.act = a.out_f32, a.out_hi, a.out_lo, rows, N, K, act
+                keep.append(ga)
+                launch(lib.ctdd_gemm_bf16, C.byref(ga), label=f"linear {label} {rows}x{K}->{N} gemm", flops=2 * rows * K * N * a.nseg)
+                return
+            if use_bf16 and N % 8 == 0 and K % 16 == 0 and getattr(m, "engine_linear", "patch") in ("gemm", "patch"):
                 # the U-Net's slab kernel run as a plain GEMM (one 1x1 segment over a rows x 1 "image"): 16-byte row-major
                 # epilogue, weights and activations staged per 128/256-row tile
                 pbk = 64 if K % 64 == 0 else 48 if K % 48 == 0 else 32 if K % 32 == 0 else 16

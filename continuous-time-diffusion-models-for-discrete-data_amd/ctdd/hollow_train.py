@@ -24,7 +24,7 @@ import torch
 
 from . import native
 from .unet_engine import SEG_1x1, _ConvArgs, _unwrap
-from .hollow_engine import _AttnArgs as _InfAttnArgs, _EmbedArgs, _LnArgs, _lib as _hollow_lib, supports  # noqa: F401
+from .hollow_engine import _AttnArgs as _InfAttnArgs, _EmbedArgs, _GemmArgs, _LnArgs, _lib as _hollow_lib, supports  # noqa: F401
 from . import unet_train
 
 _P, _I, _F, _I64, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
@@ -50,6 +50,7 @@ class _EmbedBwdArgs(C.Structure):
 
 
 _sigs_done = False
+USE_GEMM_KERNEL = True          # bf16 linears on ctdd_gemm_bf16 (K % 64 == 0, N % 8 == 0); False: the U-Net slab kernel run as a GEMM
 
 
 def lib():
@@ -91,6 +92,12 @@ def _gemm(x, w, bias, res, rows, K, N, bf16, act=0, want_hi=False, want_f32=True
     dev = x.device
     out = torch.empty((rows, N), dtype=torch.float32, device=dev) if want_f32 else None
     out_hi = torch.empty((rows, N), dtype=torch.bfloat16, device=dev) if want_hi else None
+    if bf16 and USE_GEMM_KERNEL and K % 64 == 0 and N % 8 == 0:
+        g = _GemmArgs()
+        g.a[0], g.nseg, g.w, g.bias, g.res = x.data_ptr(), 1, w.data_ptr(), _p(bias), _p(res)
+        g.out_f32, g.out_hi, g.M, g.N, g.K, g.act = _p(out), _p(out_hi), rows, N, K, act
+        _ck(l.ctdd_gemm_bf16(C.byref(g), _st()), "ctdd_gemm_bf16")
+        return out, out_hi
     a = _ConvArgs()
     a.nseg = 1
     a.seg[0].C, a.seg[0].kind = K, SEG_1x1

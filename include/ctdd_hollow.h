@@ -36,6 +36,16 @@ int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, 
 int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, void* dst_lo, int64_t dst_bs, int B, int E,
                          void* stream);                                                 /* temb into key slot 0 */
 
+/* every nn.Linear of the network (hollow_networks.py:90-447) in the bf16 modes, and its data gradient dX = dY W in training:
+ * out[M][N] = act([A_0 | A_1 | A_2][M][nseg K] . W[N][nseg K]^T + bias) + res, fp32 accumulation on the matrix cores.
+ * K % 64 == 0, N % 4 == 0; out_f32 / out_hi (bf16) / out_lo (bf16(v - hi)): any subset; act 0 none, 1 ReLU, 2 GELU (erf).
+ * Three segments against a concatenated weight are the hi / lo split-precision product [x_hi | x_lo | x_hi].[w_hi | w_hi | w_lo]. */
+typedef struct {
+  const void* a[3]; int nseg; const void* w; const float* bias; const float* res;
+  float* out_f32; void* out_hi; void* out_lo; int M, N, K, act;
+} ctdd_gemm_args;
+int ctdd_gemm_bf16(const void* gemm_args, void* stream);
+
 /* masked multi-head attention, softmax(scale q.k) v: mode 0 causal (j <= i, UniDirectionalTransformer l2r 534-560),
  * 1 anti-causal (j >= i, r2l), 2 readout over [temb | l2r | r2l] with Tk = 2 Tq + 1 (CrossAttention 204-280).
  * q/k/v rows at base + b*bs + row*rs + head*hd. */
