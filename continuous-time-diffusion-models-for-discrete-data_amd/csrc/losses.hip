@@ -843,7 +843,141 @@ __global__ __launch_bounds__(256) void k_logprob_bwd(const LpbArgs a) {
   }
 }
 
+
+// ---- reverse_prob log-probabilities and their backward with the S x S contractions on the exact-fp32 matrix instruction
+// (S % 32 == 0, per-sample tables: the training objectives of the MNIST / CIFAR hollow configs).  The generic row kernel
+// (ctdd_logprob: k_rows) runs them as fp32 FMA chains with the table streamed per row: 2.5 ms for 32 x 784 rows at S = 256.
+//   forward   P = softmax(l)  ->  acc = P q  (k_bgemm_f32, W = q^T)  ->  ll_all = log(acc + 1e-35), ll_xt = ll_all[x]
+//   backward  ga = dll / (acc + 1e-35) = dll exp(-ll_all)  ->  dp = ga q^T  (k_bgemm_f32, W = q)  ->
+//             dl[j] = p[j] (dp[j] - sum p dp)  [+ nll_scale (p[j] - [j = x0])]
+// Row kernels: 8 rows per workgroup, thread <-> state.
+__global__ __launch_bounds__(256) void k_lp_softmax(const float* __restrict__ logits, int64_t rows, int S, float* __restrict__ P) {
+  __shared__ float red[4 * LRB];
+  const int t = threadIdx.x;
+  const bool on = t < S;
+  float l[LRB], m[LRB], e[LRB], z[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const int64_t row = min((int64_t)blockIdx.x * LRB + r, rows - 1);
+    l[r] = on ? logits[(size_t)row * S + t] : -INFINITY;
+  }
+  block_max8(l, red, m);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) e[r] = on ? expf(l[r] - m[r]) : 0.0f;
+  block_sum8(e, red, z);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const int64_t row = (int64_t)blockIdx.x * LRB + r;
+    if (on && row < rows) P[(size_t)row * S + t] = e[r] / z[r];
+  }
+}
+// in place: acc -> ll_all = log(acc + 1e-35); ll_xt[row] = ll_all[row][x]
+__global__ __launch_bounds__(256) void k_lp_log(float* __restrict__ ll, const int32_t* __restrict__ x, int64_t rows, int S, float* __restrict__ ll_xt) {
+  const int t = threadIdx.x;
+  if (t >= S) return;
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const int64_t row = (int64_t)blockIdx.x * LRB + r;
+    if (row >= rows) break;
+    const float v = logf(ll[(size_t)row * S + t] + 1e-35f);
+    ll[(size_t)row * S + t] = v;
+    if (ll_xt && t == min(max(x[row], 0), S - 1)) ll_xt[row] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_lp_ga(const float* __restrict__ dll, const float* __restrict__ ll, int64_t n4, float* __restrict__ ga) {
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n4; v += (int64_t)gridDim.x * 256) {
+    const float4 g = *(const float4*)(dll + v * 4), l = *(const float4*)(ll + v * 4);
+    *(float4*)(ga + v * 4) = make_float4(g.x * expf(-l.x), g.y * expf(-l.y), g.z * expf(-l.z), g.w * expf(-l.w));
+  }
+}
+__global__ __launch_bounds__(256) void k_lp_final(const float* __restrict__ logits, const float* __restrict__ dp, const int32_t* __restrict__ x0,
+                                                  int64_t rows, int S, float nll_scale, float* __restrict__ grad, double* __restrict__ ce_rows) {
+  __shared__ float red[4 * LRB];
+  const int t = threadIdx.x;
+  const bool on = t < S;
+  float l[LRB], m[LRB], p[LRB], z[LRB], d[LRB], pd[LRB], dot[LRB];
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const int64_t row = min((int64_t)blockIdx.x * LRB + r, rows - 1);
+    l[r] = on ? logits[(size_t)row * S + t] : -INFINITY;
+    d[r] = on ? dp[(size_t)row * S + t] : 0.0f;
+  }
+  block_max8(l, red, m);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) p[r] = on ? expf(l[r] - m[r]) : 0.0f;
+  block_sum8(p, red, z);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) { p[r] = p[r] / z[r]; pd[r] = p[r] * d[r]; }
+  block_sum8(pd, red, dot);
+#pragma unroll
+  for (int r = 0; r < LRB; ++r) {
+    const int64_t row = (int64_t)blockIdx.x * LRB + r;
+    if (!on || row >= rows) continue;
+    float v = p[r] * (d[r] - dot[r]);
+    if (x0) {
+      const int xz = min(max(x0[row], 0), S - 1);
+      v += nll_scale * (p[r] - (t == xz ? 1.0f : 0.0f));
+      if (t == xz && ce_rows) ce_rows[row] = (double)nll_scale * (double)(-(l[r] - m[r] - logf(z[r])));
+    }
+    grad[(size_t)row * S + t] = v;
+  }
+}
+template <typename F>
+static int launch_bgemm(int S, dim3 gg, hipStream_t st, const float* Am, const float* Wm, float* Cm, int M) {
+  switch (S / 32) {
+    case 1: hipLaunchKernelGGL(k_bgemm_f32<1>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    case 2: hipLaunchKernelGGL(k_bgemm_f32<2>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    case 3: hipLaunchKernelGGL(k_bgemm_f32<3>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    case 4: hipLaunchKernelGGL(k_bgemm_f32<4>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    case 5: hipLaunchKernelGGL(k_bgemm_f32<5>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    case 6: hipLaunchKernelGGL(k_bgemm_f32<6>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    case 7: hipLaunchKernelGGL(k_bgemm_f32<7>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+    default: hipLaunchKernelGGL(k_bgemm_f32<8>, gg, dim3(256), 0, st, Am, Wm, Cm, M); break;
+  }
+  return finish_launch("k_bgemm_f32");
+}
+
 }  // namespace ctdd
+
+// scratch: (B, D, S) fp32 (softmax)
+extern "C" int ctdd_logprob_rp_mfma(const float* logits, const int32_t* x, const float* qt0T, int B, int D, int S, float* scratch,
+                                    float* out_ll_all, float* out_ll_xt, void* stream) {
+  CTDD_REQUIRE(logits && qt0T && scratch && out_ll_all && (x || !out_ll_xt), CTDD_EINVAL, "logprob (matrix cores): null buffer");
+  CTDD_REQUIRE(B > 0 && D > 0 && S >= 32 && S <= 256 && S % 32 == 0, CTDD_ERANGE, "logprob (matrix cores): B=%d D=%d S=%d (S %% 32 == 0, <= 256)", B, D, S);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * D;
+  const unsigned rb = (unsigned)((rows + LRB - 1) / LRB);
+  hipLaunchKernelGGL(k_lp_softmax, dim3(rb), dim3(256), 0, st, logits, rows, S, scratch);
+  if (int rc = finish_launch("k_lp_softmax")) return rc;
+  if (int rc = launch_bgemm<void>(S, dim3((D + 127) / 128, B), st, scratch, qt0T, out_ll_all, D)) return rc;   // acc[row][s] = sum_s0 P[row][s0] qT[s][s0]
+  hipLaunchKernelGGL(k_lp_log, dim3(rb), dim3(256), 0, st, out_ll_all, x, rows, S, out_ll_xt);
+  return finish_launch("k_lp_log");
+}
+// backward of the above given ll_all (its output) and dll = d loss / d ll_all; scratch: 2 x (B, D, S) fp32 (ga | dp)
+extern "C" int ctdd_logprob_rp_bwd_mfma(const float* logits, const float* qt0, const float* ll_all, const float* dll, const int32_t* x0,
+                                        float nll_scale, int B, int D, int S, float* scratch, float* grad_logits, double* ce_rows,
+                                        float* out_ce, void* stream) {
+  CTDD_REQUIRE(logits && qt0 && ll_all && dll && scratch && grad_logits, CTDD_EINVAL, "logprob bwd (matrix cores): null buffer");
+  CTDD_REQUIRE(B > 0 && D > 0 && S >= 32 && S <= 256 && S % 32 == 0, CTDD_ERANGE, "logprob bwd (matrix cores): B=%d D=%d S=%d", B, D, S);
+  CTDD_REQUIRE(!x0 || (ce_rows && out_ce), CTDD_EINVAL, "logprob bwd: the cross-entropy term needs ce_rows and out_ce");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * D, n = rows * S;
+  float* ga = scratch;
+  float* dp = scratch + n;
+  int64_t g = (n / 4 + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_lp_ga, dim3((unsigned)g), dim3(256), 0, st, dll, ll_all, n / 4, ga);
+  if (int rc = finish_launch("k_lp_ga")) return rc;
+  if (int rc = launch_bgemm<void>(S, dim3((D + 127) / 128, B), st, ga, qt0, dp, D)) return rc;                 // dp[row][s0] = sum_s ga[row][s] q[s0][s]
+  hipLaunchKernelGGL(k_lp_final, dim3((unsigned)((rows + LRB - 1) / LRB)), dim3(256), 0, st, logits, (const float*)dp, x0, rows, S, nll_scale,
+                     grad_logits, ce_rows);
+  if (int rc = finish_launch("k_lp_final")) return rc;
+  if (x0) {
+    hipLaunchKernelGGL(k_sum_rows, dim3(1), dim3(256), 0, st, (const double*)ce_rows, rows, out_ce);
+    return finish_launch("k_sum_rows");
+  }
+  return CTDD_OK;
+}
 
 extern "C" int ctdd_logprob_bwd(int logit_type, const float* logits, const float* qt0, const float* qt0T, const float* dll,
                                 const int32_t* x0, float nll_scale, int B, int D, int S, float* grad_logits, double* ce_rows,

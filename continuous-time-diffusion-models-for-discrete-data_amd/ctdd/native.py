@@ -40,6 +40,8 @@ _SIGS = {
     "ctdd_tauleap_draw": ([_P, _P, _P, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
     "ctdd_tauleap_step": ([_I, _I, _P, _P, _P, _P, _P, _F, _F, _F, _U32, _U64, _U64, _I, _I, _I, _P, _P, _P], _I),
     "ctdd_lbjf_step": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _U32, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_logprob_rp_mfma": ([_P, _P, _P, _I, _I, _I, _P, _P, _P, _P], _I),
+    "ctdd_logprob_rp_bwd_mfma": ([_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P, _P], _I),
     "ctdd_exact_step": ([_P, _P, _P, _P, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
     "ctdd_midpoint_predict": ([_I, _I, _P, _P, _P, _P, _F, _F, _F, _I, _I, _I, _P, _P], _I),
     "ctdd_lbjf_from_rates": ([_P, _P, _F, _P, _U64, _U64, _I, _I, _I, _P, _P, _P, _P], _I),
@@ -156,10 +158,23 @@ def xtilde_sample(rate, x_t, tidx=None, E_dim=None, E_val=None, seed=0, offset=0
     return dims, newval, xt
 
 
-def logprob(logits, x, qt0, logit_type, tidx=None):
+def _rp_mfma_ok(logit_type, logits, qt0):
+    N, D, S = logits.shape
+    return logit_type == "reverse_prob" and S % 32 == 0 and 32 <= S <= 256 and qt0 is not None and qt0.dim() == 3 and qt0.shape[0] == N
+
+
+def logprob(logits, x, qt0, logit_type, tidx=None, qt0T=None):
+    """get_logprob_with_logits.  qt0T given (per-sample transposed tables), reverse_prob, S % 32 == 0: the matrix-core path."""
     N, D, S = logits.shape
     ll_all = torch.empty_like(logits)
     ll_xt = torch.empty((N, D), dtype=f32, device=logits.device)
+    if qt0T is not None and _rp_mfma_ok(logit_type, logits, qt0):
+        scratch = torch.empty_like(logits)
+        rc = load().ctdd_logprob_rp_mfma(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(qt0T, f32, "qt0T"), N, D, S, _ptr(scratch),
+                                         _ptr(ll_all), _ptr(ll_xt), _stream())
+        _check(rc, "ctdd_logprob_rp_mfma")
+        _count("ctdd_logprob")
+        return ll_all, ll_xt
     rc = load().ctdd_logprob(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(qt0, f32, "qt0"),
                              _ptr(tidx, i32, "tidx"), LOGIT_TYPES[logit_type], N, D, S, _ptr(ll_all), _ptr(ll_xt),
                              _stream())
@@ -336,13 +351,22 @@ def score_elbo_loss_ll(ll_all, x0, x_tilde, reg_x, qt0, rate, eps, nll_scale):
     return out[0], grad
 
 
-def logprob_bwd(logit_type, logits, qt0, qt0T, dll, x0=None, nll_scale=0.0):
+def logprob_bwd(logit_type, logits, qt0, qt0T, dll, x0=None, nll_scale=0.0, ll_all=None):
     """d/dlogits of ll_all = get_logprob_with_logits(logits) for the reverse logit types given dll = d loss / d ll_all;
-    x0: also the cross-entropy term nll_scale * sum -log_softmax(logits)[x0] (gradient added, value returned)."""
+    x0: also the cross-entropy term nll_scale * sum -log_softmax(logits)[x0] (gradient added, value returned).
+    ll_all (the forward's output) given, reverse_prob, S % 32 == 0: the matrix-core path."""
     B, D, S = logits.shape
     grad = torch.empty_like(logits)
     ce_rows = torch.zeros((B * D,), dtype=torch.float64, device=logits.device) if x0 is not None else None
     out_ce = torch.zeros((1,), dtype=torch.float32, device=logits.device)
+    if ll_all is not None and _rp_mfma_ok(logit_type, logits, qt0):
+        scratch = torch.empty((2,) + tuple(logits.shape), dtype=torch.float32, device=logits.device)
+        _check(load().ctdd_logprob_rp_bwd_mfma(_ptr(logits, torch.float32, "logits"), _ptr(qt0, torch.float32, "qt0"), _ptr(ll_all, torch.float32, "ll_all"),
+                                               _ptr(dll, torch.float32, "dll"), _ptr(x0, torch.int32, "x0") if x0 is not None else None,
+                                               float(nll_scale), B, D, S, _ptr(scratch), _ptr(grad), _ptr(ce_rows) if ce_rows is not None else None,
+                                               _ptr(out_ce), _stream()), "ctdd_logprob_rp_bwd_mfma")
+        _count("ctdd_logprob_bwd")
+        return grad, out_ce[0]
     _check(load().ctdd_logprob_bwd(LOGIT_TYPES[logit_type], _ptr(logits, torch.float32, "logits"), _ptr(qt0, torch.float32, "qt0"),
                                    _ptr(qt0T, torch.float32, "qt0T"), _ptr(dll, torch.float32, "dll"),
                                    _ptr(x0, torch.int32, "x0") if x0 is not None else None, float(nll_scale), B, D, S, _ptr(grad),

@@ -243,9 +243,10 @@ class _CrmRevFn(torch.autograd.Function):
         lg = logits.detach().float().contiguous()
         xti = xt.to(torch.int32).contiguous()
         tidx = torch.arange(lg.shape[0], dtype=torch.int32, device=lg.device)
-        ll_all, _ = native.logprob(lg, xti, qt0, logit_type, tidx)
+        ll_all, _ = native.logprob(lg, xti, qt0, logit_type, tidx, qt0T=qt0T)
         val, dll = native.crm_loss_ll(ll_all, xti, qt0 if loss_type == "elbo" else None, loss_type, scale)
-        grad, ce = native.logprob_bwd(logit_type, lg, qt0, qt0T, dll, None if x0 is None else x0.to(torch.int32).contiguous(), nll_scale)
+        grad, ce = native.logprob_bwd(logit_type, lg, qt0, qt0T, dll, None if x0 is None else x0.to(torch.int32).contiguous(), nll_scale,
+                                      ll_all=ll_all)
         ctx.save_for_backward(grad)
         return val if x0 is None else val + ce
 
@@ -263,9 +264,9 @@ class _ScoreElboRevFn(torch.autograd.Function):
         lg = logits.detach().float().contiguous()
         i32 = lambda t: t.to(torch.int32).contiguous()
         tidx = torch.arange(lg.shape[0], dtype=torch.int32, device=lg.device)
-        ll_all, _ = native.logprob(lg, i32(x_tilde), qt0, logit_type, tidx)
+        ll_all, _ = native.logprob(lg, i32(x_tilde), qt0, logit_type, tidx, qt0T=qt0T)
         val, dll = native.score_elbo_loss_ll(ll_all, i32(x0), i32(x_tilde), i32(reg_x), qt0, rate.contiguous(), eps, nll_scale)
-        grad, _ = native.logprob_bwd(logit_type, lg, qt0, qt0T, dll)
+        grad, _ = native.logprob_bwd(logit_type, lg, qt0, qt0T, dll, ll_all=ll_all)
         ctx.save_for_backward(grad)
         return val
 

@@ -215,6 +215,17 @@ int ctdd_score_elbo_loss(const float* logits, const int32_t* x0, const int32_t* 
                          const float* qt0, const float* rate, int B, int D, int S, float eps, float nll_scale,
                          void* scratch, float* grad_logits, float* out_loss, void* stream);
 
+/* The same two for logit_type reverse_prob with per-sample tables and S % 32 == 0 (<= 256), the S x S contractions on the
+ * exact-fp32 matrix instruction (model_utils.py:42-48 and its autograd backward):
+ * forward  ll_all = log(softmax(logits) @ q_{t|0} + 1e-35), ll_xt = ll_all[x]   (qt0T (B,S,S) = the transposed tables; scratch (B,D,S) fp32);
+ * backward d/dlogits given ll_all (the forward's output) and dll = d loss / d ll_all, + the cross-entropy term as ctdd_logprob_bwd
+ *          (scratch 2 x (B,D,S) fp32). */
+int ctdd_logprob_rp_mfma(const float* logits, const int32_t* x, const float* qt0T, int B, int D, int S, float* scratch,
+                         float* out_ll_all, float* out_ll_xt, void* stream);
+int ctdd_logprob_rp_bwd_mfma(const float* logits, const float* qt0, const float* ll_all, const float* dll, const int32_t* x0,
+                             float nll_scale, int B, int D, int S, float* scratch, float* grad_logits, double* ce_rows,
+                             float* out_ce, void* stream);
+
 /* ---- the same objectives for logit_type 'reverse_prob' / 'reverse_logscale' (model_utils.py:42-56; every shipped hollow
  * config uses reverse_prob): three launches chained on the device --
  *   ctdd_logprob (above)            logits -> ll_all = log p_t(. | x^{\d})

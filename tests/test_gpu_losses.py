@@ -173,3 +173,28 @@ def test_crm_reverse_logit_types_match_oracle_formulas(S, D, logit_type, loss_ty
     grad, = torch.autograd.grad(val, lg)
     np.testing.assert_allclose(val.item(), want.item(), rtol=3e-5)
     np.testing.assert_allclose(grad.cpu().numpy(), wgrad.numpy(), rtol=5e-4, atol=1e-6 * wgrad.abs().max().item() + 1e-9)
+
+
+@pytest.mark.parametrize("S,D,B", [(256, 50, 3), (32, 37, 4), (96, 130, 2)])
+def test_logprob_reverse_prob_matrix_core_path_matches_generic(S, D, B):
+    """ctdd_logprob_rp_mfma / ctdd_logprob_rp_bwd_mfma (S x S contractions on v_mfma_f32_32x32x2_f32) against the generic row
+    kernels (fp32 FMA chains) on the same inputs: forward log-probabilities, backward d/dlogits with the cross-entropy term."""
+    from ctdd import native
+    g = torch.Generator().manual_seed(S + D)
+    logits = (torch.randn(B, D, S, generator=g) * 2).cuda()
+    x = torch.randint(0, S, (B, D), generator=g).to(torch.int32).cuda()
+    x0 = torch.randint(0, S, (B, D), generator=g).to(torch.int32).cuda()
+    q = torch.softmax(torch.randn(B, S, S, generator=g) * 3, dim=-1).cuda().contiguous()        # row-stochastic tables
+    qT = q.transpose(1, 2).contiguous()
+    tidx = torch.arange(B, dtype=torch.int32, device="cuda")
+    ll_ref, llx_ref = native.logprob(logits, x, q, "reverse_prob", tidx)
+    ll, llx = native.logprob(logits, x, q, "reverse_prob", tidx, qt0T=qT)
+    np.testing.assert_allclose(ll.cpu().numpy(), ll_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(llx.cpu().numpy(), llx_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    dll = torch.randn(B, D, S, generator=g).cuda()
+    for x0_, w in ((None, 0.0), (x0, 0.37)):
+        g_ref, ce_ref = native.logprob_bwd("reverse_prob", logits, q, qT, dll, x0_, w)
+        g_new, ce_new = native.logprob_bwd("reverse_prob", logits, q, qT, dll, x0_, w, ll_all=ll_ref)
+        scale = float(g_ref.abs().max())
+        assert float((g_new - g_ref).abs().max()) < 2e-5 * scale
+        np.testing.assert_allclose(float(ce_new), float(ce_ref), rtol=1e-5, atol=1e-6)
