@@ -3,13 +3,16 @@
 // 90-132 (FiLM residual readout), 668-755 (embedding)), plus the training-mode forward pieces the inference kernels of
 // hollow_kernels.hip do not have: dropout inside attention and after activations.
 //
-//   LayerNorm (+ add, + FiLM) backward      k_hollow_ln_bwd       one wave per run of rows of one sample; column sums in registers
-//   attention forward with dropout          k_hollow_attn_train   thread = query (fp32 FMA, online softmax), writes (max, sum) per query
-//   attention backward                      k_hollow_attn_bwd_q   thread = query: D_i = dO.O, dQ;   k_hollow_attn_bwd_kv  thread = key:
-//                                           dK, dV over the queries that see it -- no atomics, the scores are recomputed in both
-//   ReLU / GELU (+ dropout) forward, backward   k_hollow_act
+//   LayerNorm (+ add, + FiLM) backward      k_hollow_ln_bwd<KN>   four rows in flight per wave; dgamma / dbeta through LDS into replicated accumulators
+//   attention, fp32 FMA (parity mode)       k_hollow_attn_train (thread = query, online softmax, writes (max, sum) per query),
+//                                           k_hollow_attn_bwd_q (thread = query: D_i = dO.O, dQ), k_hollow_attn_bwd_kv (thread = key: dK, dV)
+//   attention, matrix cores (bf16 mode)     k_hollow_attn_q_mfma<HD, BWD, NW> (forward / dQ), k_hollow_attn_kv_mfma<HD, NW> (dK, dV)
+//                                           -- no atomics, the scores are recomputed in both backward kernels; the same dropout masks
+//   ReLU / GELU (+ dropout)                 k_hollow_act (fp32), k_hollow_relu_bf16 (the bf16-only MLP hidden tensor)
+//   dropout (+ residual, + bf16 copy)       k_hollow_dropout
+//   bias gradients                          k_hollow_colsum (two-stage column sums)
 //   embedding backward                      k_hollow_embed_bwd
-// The linear layers' gradients run on the U-Net kernels (ctdd_unet_conv* with transposed weights, ctdd_unet_wgrad kind 1x1).
+// The linear layers run on gemm_kernels.hip (bf16) / the U-Net's fp32 GEMM kernel, their weight gradients on ctdd_unet_wgrad (kind 1x1).
 // Dropout masks are Philox(seed, step * 4096 + layer, element) (common.hpp), regenerated in backward.
 #include "common.hpp"
 #ifndef CTDD_ATT_NW

@@ -2,20 +2,24 @@
 TAUnSDDM/lib/networks/hollow_networks.py:668-755 and the blocks it is built from).
 
 `HollowTrainer(model)(x, t)` computes the logits of a `BidirectionalTransformer2` with every operation a libctdd launch and
-autograd as the tape only: each operation is a `torch.autograd.Function` whose forward and backward call the C ABI
-(include/ctdd_hollow.h, ctdd_hollow_train.h, ctdd_unet.h, ctdd_unet_train.h):
+autograd as the tape only: each node is a `torch.autograd.Function` whose forward and backward call the C ABI
+(include/ctdd_hollow.h, ctdd_hollow_train.h, ctdd_unet.h, ctdd_unet_train.h) -- one Function per prenorm attention block and
+per feed-forward block (`AttnBlockFn`, `MlpBlockFn`: hand-scheduled backward), per-op Functions for the once-per-network readout:
 
-  linear layers      forward / data gradient: the implicit-GEMM kernels (`ctdd_unet_conv_patch` bf16 operands, `ctdd_unet_conv`
-                     exact fp32) -- the data gradient is the same GEMM with the transposed weight; weight gradient
-                     `ctdd_unet_wgrad` (kind 1x1: tokens are the contraction index), bias gradient `ctdd_unet_colsum`
-  LayerNorm (+FiLM)  `ctdd_hollow_layernorm` / `ctdd_hollow_layernorm_bwd`
-  attention          `ctdd_hollow_attention_train` (dropout on the probabilities inside the kernel) / `ctdd_hollow_attention_bwd`
-  ReLU / GELU, dropout, embedding, l2r + r2l   `ctdd_hollow_act`, `ctdd_unet_dropout`, `ctdd_hollow_embed(_bwd)`, `ctdd_hollow_add`
+  linear layers      forward / data gradient (the same GEMM with the packed transposed weight): `ctdd_gemm_bf16` (bf16 operands),
+                     `ctdd_unet_conv` (exact fp32);  weight gradient `ctdd_unet_wgrad` (kind 1x1: tokens are the contraction index);
+                     bias gradient `ctdd_hollow_colsum` + `ctdd_unet_sum_batch`;  operands of all weights by one
+                     `ctdd_unet_pack_weights` launch per forward
+  LayerNorm (+FiLM)  `ctdd_hollow_layernorm` / `ctdd_hollow_layernorm_bwd` (adds the residual stream's gradient)
+  attention          `ctdd_hollow_attention_train_bf16` / `_bwd_bf16` (matrix cores; dropout on the probabilities inside the
+                     kernels), `ctdd_hollow_attention_train` / `_bwd` (fp32 FMA: the parity mode, other head dimensions)
+  ReLU / GELU, dropout (+ residual, + bf16 copy), embedding, l2r + r2l
+                     `ctdd_hollow_relu_bf16`, `ctdd_hollow_act`, `ctdd_hollow_dropout`, `ctdd_hollow_embed(_bwd)`, `ctdd_hollow_add`
 
 Parameters enter the Functions directly, so their gradients are ordinary autograd gradients (DistributedDataParallel hooks
 work unchanged).  Dropout masks are Philox(seed, step, layer, element): the backward of a step regenerates the forward's.
-precision "fp32": exact-fp32 matrix instructions everywhere (parity mode); "bf16": bf16 GEMM operands, fp32 accumulation,
-fp32 attention / LayerNorm / residual streams.
+precision "fp32": exact-fp32 matrix instructions everywhere (parity mode); "bf16": bf16 GEMM / attention operands, fp32
+accumulation, fp32 softmax / LayerNorm / residual streams, the (rows, mlp_dim) hidden tensor in bf16 only.
 """
 import ctypes as C
 import math
@@ -152,7 +156,7 @@ def _wt_op(w, bf16, ld=None):
     return wt
 
 
-_tables, _ones_cache = {}, {}
+_tables = {}
 
 
 def _device_table(raw, dev):
@@ -164,14 +168,6 @@ def _device_table(raw, dev):
         if len(_tables) > 8192:
             _tables.clear()
         t = _tables[key] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-    return t
-
-
-def _ones(rows, bf16, dev):
-    key = (rows, bf16, dev.index)
-    t = _ones_cache.get(key)
-    if t is None:
-        t = _ones_cache[key] = torch.ones((rows, 8), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
     return t
 
 
