@@ -106,7 +106,7 @@ def test_hollow_train_matches_autograd_maze_size():
     assert float((out - out_ref).abs().max()) < 2e-4 * max(1.0, float(out_ref.abs().max()))
     # 16 blocks deep, ~1e6 ReLU pre-activations per layer: a few lie within rounding of zero and flip between two fp32
     # evaluations, moving single gradient entries by percents of the range.  Against a float64 evaluation of the module
-    # (scratch/hollow_grad_f64.py) torch's own fp32 gradients are off by up to 3.1e-3 in relative L2 and 3.0e-2 in max-abs,
+    # (tools/hollow_grad_f64.py) torch's own fp32 gradients are off by up to 3.1e-3 in relative L2 and 3.0e-2 in max-abs,
     # this path by 4.9e-3 / 3.2e-2; the tiny nets above (no such flips) hold 1e-4 max-abs.
     _compare(g_hip, g_ref, 1e-2, l2=True)
     out_b, g_b = _grads(model, lambda: run(HollowTrainer(model, precision="bf16")))

@@ -1,0 +1,33 @@
+"""scratch: maze hollow ScoreElbo training step (forward + backward), torch module vs the HIP training path."""
+import sys, time
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "continuous-time-diffusion-models-for-discrete-data_amd"))
+import torch
+import lib.models.models  # noqa
+import lib.losses.losses  # noqa
+import lib.models.model_utils as mu
+import lib.losses.losses_utils as lu
+from config.maze_config.config_hollow_maze import get_config
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+for engine, prec in (("torch", None), ("hip", "bf16"), ("hip", "fp32")):
+    cfg = get_config(); cfg.device = "cuda"
+    cfg.model.update(engine=engine)
+    if prec: cfg.model.engine_train_precision = prec
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    loss_fn = lu.get_loss(cfg)
+    x = torch.randint(0, 3, (B, 225), device="cuda")
+    state = {"model": model, "n_iter": 0}
+    def step():
+        for p in model.parameters(): p.grad = None
+        l = loss_fn.calc_loss(x, state); l.backward(); return l
+    for _ in range(5): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 20
+    for _ in range(n): l = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    # forward only
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): l = loss_fn.calc_loss(x, state)
+    torch.cuda.synchronize(); df = (time.perf_counter() - t0) / n
+    print(f"{engine:5s} {prec or 'fp32':5s} B={B}: fwd+bwd {dt*1e3:8.2f} ms   fwd {df*1e3:8.2f} ms   loss {float(l):.4f}", flush=True)
