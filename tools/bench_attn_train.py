@@ -1,4 +1,4 @@
-"""scratch: matrix-core training attention kernels alone, graph-timed, over batch size (latency vs throughput)."""
+"""matrix-core training attention kernels alone, graph-timed, over batch size (latency vs throughput)."""
 import sys, os
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discrete-data_amd')]

@@ -1,4 +1,4 @@
-"""scratch: the hollow blocks' forward / data-gradient GEMMs (rows = 28800, bf16 operands), graph-timed."""
+"""the hollow blocks' forward / data-gradient GEMMs (rows = 28800, bf16 operands), graph-timed."""
 import sys, os
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discrete-data_amd')]

@@ -1,4 +1,4 @@
-"""scratch: the hollow blocks' weight-gradient launches (rows = 28800), graph-timed, over M-split widths."""
+"""the hollow blocks' weight-gradient launches (rows = 28800), graph-timed, over M-split widths."""
 import sys, os
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discrete-data_amd')]

@@ -1,6 +1,8 @@
-"""scratch: fp32 HIP gradients and fp32 torch gradients of the maze hollow net against a float64 evaluation of the module."""
+"""fp32 HIP gradients and fp32 torch gradients of the maze hollow net against a float64 evaluation of the module."""
 import copy, sys
-sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "continuous-time-diffusion-models-for-discrete-data_amd"))
+import os
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_R, os.path.join(_R, "continuous-time-diffusion-models-for-discrete-data_amd")]
 import torch
 import lib.models.models  # noqa
 import lib.models.model_utils as mu

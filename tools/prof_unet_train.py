@@ -1,4 +1,4 @@
-"""scratch: profile target -- MNIST tauLDR CT-ELBO training steps (B = 64) on the HIP training plan, bf16."""
+"""profile target -- MNIST tauLDR CT-ELBO training steps (B = 64) on the HIP training plan, bf16."""
 import sys, os
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discrete-data_amd')]

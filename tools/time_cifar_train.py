@@ -1,4 +1,4 @@
-"""scratch: CIFAR-10 tauLDR U-Net training step (CTElboLambda config), torch autograd vs the HIP training plan."""
+"""CIFAR-10 tauLDR U-Net training step (CTElboLambda config), torch autograd vs the HIP training plan."""
 import sys, os, time
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discrete-data_amd')]

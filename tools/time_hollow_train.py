@@ -1,6 +1,8 @@
-"""scratch: maze hollow ScoreElbo training step (forward + backward), torch module vs the HIP training path."""
+"""maze hollow ScoreElbo training step (forward + backward), torch module vs the HIP training path."""
 import sys, time
-sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "continuous-time-diffusion-models-for-discrete-data_amd"))
+import os
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_R, os.path.join(_R, "continuous-time-diffusion-models-for-discrete-data_amd")]
 import torch
 import lib.models.models  # noqa
 import lib.losses.losses  # noqa

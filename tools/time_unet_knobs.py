@@ -1,4 +1,4 @@
-"""scratch: MNIST U-Net training step (B=64, bf16 plan) over weight-gradient scheduling knobs."""
+"""MNIST U-Net training step (B=64, bf16 plan) over weight-gradient scheduling knobs."""
 import sys, os, time
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discrete-data_amd')]
