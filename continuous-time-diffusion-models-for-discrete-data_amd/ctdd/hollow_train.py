@@ -650,7 +650,7 @@ class HollowTrainer:
             raise native.CtddError("HollowTrainer needs the model on a GPU")
         lib()
         self.rng = torch.zeros(2, dtype=torch.int64, device=self.dev)
-        self.rng[0] = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+        self.rng[0] = native.dropout_seed()
         self.pe = None
         self._pack_key, self._packs, self._pack_tab, self._pack_total = None, {}, None, 0
 

@@ -315,6 +315,19 @@ def crm_loss(logits, xt, x0, qt0, loss_type, scale, nll_scale):
     return out[0], grad
 
 
+def dropout_seed():
+    """Seed of a network's dropout stream: drawn from torch's CPU generator (reproducible under torch.manual_seed) and mixed with
+    the data-parallel rank, so that ranks seeded alike still drop different units."""
+    seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            seed = (seed + dist.get_rank() * 0x9E3779B97F4A7C15) % (2**62)
+    except Exception:
+        pass
+    return seed
+
+
 LAUNCH_COUNTS = {}      # entry point -> calls (tests assert that an objective really ran through the HIP path)
 
 

@@ -643,7 +643,7 @@ class UNetEngine:
                 tc = unet_train.TrainCtx(self, B, dropout)
                 st = self._build(B, x.dtype, tc=tc)
                 st.gen, st.busy, st.fgraph, st.bgraph = 0, False, None, None
-                tc.rng[0] = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+                tc.rng[0] = native.dropout_seed()
                 self._train_warm_and_capture(st, x, times)
                 pool.append(st)
         tc = st.tc
