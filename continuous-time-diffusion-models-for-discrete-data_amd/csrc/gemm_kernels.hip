@@ -109,12 +109,11 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs a) {
     if (nchunks > 1) fetch(1, ra[DEEP], rw[DEEP]);
     stash(0, ra[0], rw[0]);
     __syncthreads();
-    for (int c = 0; c < nchunks; c += 2) {
-      if (c + 2 < nchunks) fetch(c + 2, ra[0], rw[0]);
+    for (int c = 0; c < nchunks; c += 2) {                      // nchunks is even (the launcher picks KC so): no exit in mid-body --
+      if (c + 2 < nchunks) fetch(c + 2, ra[0], rw[0]);         // with one, the compiler kept two copies of the accumulators
       compute(0);
-      if (c + 1 < nchunks) stash(1, ra[DEEP], rw[DEEP]);
+      stash(1, ra[DEEP], rw[DEEP]);
       __syncthreads();
-      if (c + 1 >= nchunks) break;
       if (c + 3 < nchunks) fetch(c + 3, ra[DEEP], rw[DEEP]);
       compute(1);
       if (c + 2 < nchunks) stash(0, ra[0], rw[0]);
@@ -184,13 +183,28 @@ extern "C" int ctdd_gemm_bf16(const void* args_, void* stream) {
   CTDD_REQUIRE(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.K > 0 && a.K % 64 == 0, CTDD_ERANGE, "gemm: M=%d N=%d K=%d (K %% 64 == 0, N %% 4 == 0)", a.M, a.N, a.K);
   CTDD_REQUIRE(a.act >= 0 && a.act <= 2, CTDD_EINVAL, "gemm: act %d", a.act);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t wg22 = ((int64_t)a.M + 127) / 128 * ((a.N + 127) / 128);
+  // Tile / chunk selection from measurements (scratch bench over the training and inference shapes, rows ~ 3e4):
+  //   N <= 128               64 x 128 tiles, two chunks of 64 in flight            (K = 1024: 21.5 us vs 29.3 with 128 x 128 tiles)
+  //   K' <= 128, N <= 512    128 x 128 tiles, chunks of 32, one in flight           (qkv 16.8 vs 18.0)
+  //   K' <= 256, wider N     64 x 128 tiles, chunks of 32                           (fc1 / du 31.1 vs 36.2)
+  //   K' >= 512              128 x 128 tiles, two chunks of 64 (32) in flight       (the hi / lo split products: 450-500 TFLOP/s)
+  // The two-in-flight loop needs an even chunk count: K % 64 == 0 makes it so at chunks of 32, at 64 only for even nseg K / 64.
+  const int Kt = a.nseg * a.K;
+  const bool even64 = (Kt / 64) % 2 == 0;
+  const dim3 g11((unsigned)((a.M + 63) / 64), (a.N + 63) / 64), g12((unsigned)((a.M + 63) / 64), (a.N + 127) / 128),
+             g22((unsigned)((a.M + 127) / 128), (a.N + 127) / 128);
   if (a.N <= 64) {
-    hipLaunchKernelGGL((k_gemm_bf16<1, 1, 64, true>), dim3((unsigned)((a.M + 63) / 64), (a.N + 63) / 64), dim3(256), 0, st, a);
-  } else if (a.nseg * a.K <= 128 && a.N >= 256 && wg22 >= 512) {
-    hipLaunchKernelGGL((k_gemm_bf16<2, 2, 32, false>), dim3((unsigned)((a.M + 127) / 128), (a.N + 127) / 128), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_gemm_bf16<1, 1, 32, true>), g11, dim3(256), 0, st, a);
+  } else if (a.N <= 128) {
+    if (even64) hipLaunchKernelGGL((k_gemm_bf16<1, 2, 64, true>), g12, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_bf16<1, 2, 32, true>), g12, dim3(256), 0, st, a);
+  } else if (Kt <= 128 && a.N <= 512) {
+    hipLaunchKernelGGL((k_gemm_bf16<2, 2, 32, false>), g22, dim3(256), 0, st, a);
+  } else if (Kt <= 256) {
+    hipLaunchKernelGGL((k_gemm_bf16<1, 2, 32, true>), g12, dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((k_gemm_bf16<1, 2, 64, true>), dim3((unsigned)((a.M + 63) / 64), (a.N + 127) / 128), dim3(256), 0, st, a);
+    if (even64) hipLaunchKernelGGL((k_gemm_bf16<2, 2, 64, true>), g22, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_bf16<2, 2, 32, true>), g22, dim3(256), 0, st, a);
   }
   return finish_launch("k_gemm_bf16");
 }
