@@ -169,10 +169,10 @@ class HollowEngine:
             else:
                 bk = 32 if K % 32 == 0 else 16
                 bnt = 1 if bk == 16 else (3 if N % 96 == 0 else 4 if N % 128 == 0 else 1)
-            if use_bf16 and N % 8 == 0 and K % 64 == 0 and getattr(m, "engine_linear", "patch") == "gemm":
-                # the plain GEMM kernel of the training path (csrc/gemm_kernels.hip); the hi / lo split product is three A segments
-                # against the concatenated weight.  Opt-in (model.engine_linear = "gemm"): at the inference shapes (K' = 3 K, 5e4 rows) the
-                # tuned slab kernel below measured the same or slightly better (MNIST hollow forward: linears 9.2 vs 9.5 ms)
+            if use_bf16 and N % 8 == 0 and K % 64 == 0 and getattr(m, "engine_linear", "gemm") == "gemm":
+                # the plain GEMM kernel (csrc/gemm_kernels.hip); the hi / lo split product is three A segments against the
+                # concatenated weight.  MNIST hollow forward, batch 64: linears 9.2 ms on the slab kernel below (model.engine_linear =
+                # "patch") -> 7.7 ms; maze batch 128: forward 6.35 -> 5.52 ms
                 ga = _GemmArgs()
                 ga.nseg, ga.w, ga.bias, ga.res = a.nseg, a.w_hi, a.bias, a.res_f32
                 for si in range(a.nseg):
@@ -181,7 +181,7 @@ class HollowEngine:
                 keep.append(ga)
                 launch(lib.ctdd_gemm_bf16, C.byref(ga), label=f"linear {label} {rows}x{K}->{N} gemm", flops=2 * rows * K * N * a.nseg)
                 return
-            if use_bf16 and N % 8 == 0 and K % 16 == 0 and getattr(m, "engine_linear", "patch") in ("gemm", "patch"):
+            if use_bf16 and N % 8 == 0 and K % 16 == 0 and getattr(m, "engine_linear", "gemm") in ("gemm", "patch"):
                 # the U-Net's slab kernel run as a plain GEMM (one 1x1 segment over a rows x 1 "image"): 16-byte row-major
                 # epilogue, weights and activations staged per 128/256-row tile
                 pbk = 64 if K % 64 == 0 else 48 if K % 48 == 0 else 32 if K % 32 == 0 else 16
