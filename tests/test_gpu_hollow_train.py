@@ -238,3 +238,46 @@ def test_hollow_score_elbo_training_step_matches_torch():
             assert model._trainer is not None
     assert abs(res["hip"][0] - res["torch"][0]) < 1e-4 * max(1.0, abs(res["torch"][0]))
     _compare(res["hip"][1], res["torch"][1], 2e-3)
+
+
+def test_hollow_elementwise_training_kernels():
+    """ctdd_hollow_colsum (two-stage column sums), ctdd_hollow_dropout (mask + residual + bf16 copy in one pass) and
+    ctdd_hollow_relu_bf16 (bf16-only ReLU + dropout whose saved output is its own backward mask) against torch / against
+    the fp32 kernel ctdd_hollow_act on the same Philox masks."""
+    from ctdd import hollow_train as ht
+    torch.manual_seed(2)
+    rng = torch.tensor([77, 3], dtype=torch.int64, device="cuda")
+    # column sums: fp32 and bf16 inputs, N not a multiple of the vector width's row split, padded leading dimension
+    for rows, N, ld, bf in ((5000, 136, 136, False), (28800, 1024, 1024, True), (300, 3, 16, True), (777, 384, 384, False)):
+        x = torch.randn((rows, ld), device="cuda")
+        x[:, N:] = 0.0
+        xo = x.to(torch.bfloat16) if bf else x
+        got = ht._colsum(xo, rows, N, ld, bf)
+        ref = xo.float()[:, :N].double().sum(0)
+        assert float((got.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())) + 1e-3
+    # dropout (+ residual, + bf16 copy): both outputs carry the same mask; p = 0 is the plain add / cast
+    x, r = torch.randn((640, 128), device="cuda"), torch.randn((640, 128), device="cuda")
+    p = 0.3
+    o32, o16 = ht._dropout(x, p, rng, 9, res=r, want_f32=True, want_hi=True)
+    kept = (o32 - r).abs() > 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+    assert torch.allclose((o32 - r)[kept], (x / (1 - p))[kept], rtol=1e-5, atol=1e-5)
+    assert torch.equal(o16, o32.to(torch.bfloat16))
+    again, _ = ht._dropout(x, p, rng, 9)
+    assert torch.equal(again != 0, kept)                                         # same (seed, step, layer) -> same mask
+    other, _ = ht._dropout(x, p, rng, 10)
+    assert not torch.equal(other != 0, kept)
+    plain, cast = ht._dropout(x, 0.0, None, 0, res=r, want_f32=True, want_hi=True)
+    assert torch.equal(plain, x + r) and torch.equal(cast, (x + r).to(torch.bfloat16))
+    # bf16 ReLU + dropout: forward equals the fp32 kernel's result on the bf16-rounded input (same element -> mask mapping),
+    # backward = gradient * [saved output != 0] / (1 - p) equals the fp32 kernel's backward
+    pre = torch.randn((512, 1024), device="cuda").to(torch.bfloat16)
+    u = pre.clone()
+    ht._ck(ht.lib().ctdd_hollow_relu_bf16(u.data_ptr(), None, u.data_ptr(), u.numel(), p, rng.data_ptr(), 4, ht._st()), "relu_bf16")
+    u_ref, _ = ht._act(pre.float().contiguous(), None, 1, p, rng, 4)
+    assert torch.equal(u, u_ref.to(torch.bfloat16))
+    du = torch.randn((512, 1024), device="cuda").to(torch.bfloat16)
+    dpre = du.clone()
+    ht._ck(ht.lib().ctdd_hollow_relu_bf16(dpre.data_ptr(), u.data_ptr(), dpre.data_ptr(), dpre.numel(), p, None, 0, ht._st()), "relu_bf16 bwd")
+    d_ref, _ = ht._act(pre.float().contiguous(), du.float().contiguous(), 1, p, rng, 4)
+    assert torch.equal(dpre, d_ref.to(torch.bfloat16))
