@@ -148,8 +148,9 @@ def test_hollow_train_dropout_masks_are_consistent(golden):
         again = float(loss_at(10))
         other = float(loss_at(11))
     fd = (lp - lm) / (2 * eps)
-    assert abs(again - float(l0)) < 1e-6 * max(1.0, abs(float(l0)))          # same step -> same masks
-    assert abs(other - float(l0)) > 1e-4 * max(1.0, abs(float(l0)))          # next step -> different masks
+    l0v = float(l0.detach())
+    assert abs(again - l0v) < 1e-6 * max(1.0, abs(l0v))                      # same step -> same masks
+    assert abs(other - l0v) > 1e-4 * max(1.0, abs(l0v))                      # next step -> different masks
     assert abs(fd - analytic) < 2e-2 * max(abs(analytic), 1.0), (fd, analytic)
     model.eval()
     with torch.enable_grad():
@@ -281,3 +282,39 @@ def test_hollow_elementwise_training_kernels():
     ht._ck(ht.lib().ctdd_hollow_relu_bf16(dpre.data_ptr(), u.data_ptr(), dpre.data_ptr(), dpre.numel(), p, None, 0, ht._st()), "relu_bf16 bwd")
     d_ref, _ = ht._act(pre.float().contiguous(), du.float().contiguous(), 1, p, rng, 4)
     assert torch.equal(dpre, d_ref.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("E", [32, 128, 256, 512])
+@pytest.mark.parametrize("with_y,with_film,with_res", [(False, False, True), (True, True, False), (True, False, True)])
+def test_hollow_layernorm_backward_kernel(E, with_y, with_film, with_res):
+    """ctdd_hollow_layernorm_bwd (all three column-count instantiations: E <= 128, <= 256, <= 512) against autograd of
+    FiLM(LayerNorm(x + y)): dx (+ the residual gradient added out of place), dgamma / dbeta through the replicated
+    accumulators, the per-sample FiLM gradients."""
+    from ctdd import hollow_train as ht
+    torch.manual_seed(E + with_y)
+    B, T = 3, 37
+    x = torch.randn(B, T, E, device="cuda", requires_grad=True)
+    y = torch.randn(B, T, E, device="cuda", requires_grad=True) if with_y else None
+    gamma = (1 + 0.1 * torch.randn(E, device="cuda")).requires_grad_(True)
+    beta = (0.1 * torch.randn(E, device="cuda")).requires_grad_(True)
+    film = torch.randn(B, 2 * E, device="cuda", requires_grad=True) if with_film else None
+    dout = torch.randn(B, T, E, device="cuda")
+    dres = torch.randn(B, T, E, device="cuda") if with_res else None
+    h = x + y if with_y else x
+    z = torch.nn.functional.layer_norm(h, (E,), gamma, beta, 1e-5)
+    if with_film:
+        z = film[:, None, :E] * z + film[:, None, E:]
+    z.backward(dout)
+    out, _ = ht._layernorm(x.detach(), None if y is None else y.detach(), gamma.detach(), beta.detach(), None if film is None else film.detach(), 1e-5)
+    assert float((out - z.detach()).abs().max()) < 1e-5 * max(1.0, float(z.detach().abs().max()))
+    dx, dg, db, dfilm = ht._layernorm_bwd(x.detach(), None if y is None else y.detach(), gamma.detach(), beta.detach(),
+                                          None if film is None else film.detach(), 1e-5, dout, dres=dres)
+    ref_dx = x.grad + (dres if with_res else 0)
+    tol = lambda r: 2e-5 * max(1.0, float(r.abs().max()))
+    assert float((dx - ref_dx).abs().max()) < tol(ref_dx)
+    if with_y:
+        assert float((y.grad - x.grad).abs().max()) == 0.0                         # (the same gradient flows to both summands)
+    assert float((dg - gamma.grad).abs().max()) < tol(gamma.grad)
+    assert float((db - beta.grad).abs().max()) < tol(beta.grad)
+    if with_film:
+        assert float((dfilm - film.grad).abs().max()) < tol(film.grad)
