@@ -234,7 +234,7 @@ def test_hollow_score_elbo_training_step_matches_torch():
         for p in model.parameters():
             p.grad = None
         l.backward()
-        res[engine] = (float(l), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        res[engine] = (float(l.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
         if engine == "hip":
             assert model._trainer is not None
     assert abs(res["hip"][0] - res["torch"][0]) < 1e-4 * max(1.0, abs(res["torch"][0]))
