@@ -318,3 +318,37 @@ def test_hollow_layernorm_backward_kernel(E, with_y, with_film, with_res):
     assert float((db - beta.grad).abs().max()) < tol(beta.grad)
     if with_film:
         assert float((dfilm - film.grad).abs().max()) < tol(film.grad)
+
+
+def test_hollow_mnist_config_catrmnll_step_matches_torch():
+    """BASELINE config 3 (MNIST SDDM hollow, D = 784, S = 256, E = 256, head dimension 32; CatRMNLL with reverse_prob logits) at
+    reduced depth, batch 2, dropout 0: loss value and every parameter gradient of the HIP path (fp32 training mode; the
+    objective's softmax @ q contractions on the exact-fp32 matrix instruction) against the torch module + torch objective."""
+    import lib.models.models  # noqa: F401
+    import lib.losses.losses  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.losses.losses_utils as lu
+    from config.mnist_config.config_hollow_mnist import get_config
+    from ctdd import native
+    res = {}
+    for engine in ("torch", "hip"):
+        cfg = get_config()
+        cfg.device = "cuda"
+        cfg.loss.name = "CatRMNLL"
+        cfg.loss.fused = engine == "hip"                       # torch side: the reference formula on device ops
+        cfg.model.update(dropout_rate=0.0, attention_dropout_rate=0.0, num_layers=1, engine=engine, engine_train_precision="fp32")
+        torch.manual_seed(0)
+        model = mu.create_model(cfg, torch.device("cuda"))
+        loss_fn = lu.get_loss(cfg)
+        x = torch.randint(0, 256, (2, 784), device="cuda")
+        torch.manual_seed(11)
+        before = native.LAUNCH_COUNTS.get("ctdd_logprob_bwd", 0)
+        l = loss_fn.calc_loss(x, {"model": model, "n_iter": 0})
+        for p in model.parameters():
+            p.grad = None
+        l.backward()
+        res[engine] = (float(l.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        if engine == "hip":
+            assert model._trainer is not None and native.LAUNCH_COUNTS.get("ctdd_logprob_bwd", 0) == before + 1
+    assert abs(res["hip"][0] - res["torch"][0]) < 2e-4 * max(1.0, abs(res["torch"][0]))
+    _compare(res["hip"][1], res["torch"][1], 5e-3, l2=True)
