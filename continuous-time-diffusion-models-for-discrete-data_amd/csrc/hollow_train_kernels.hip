@@ -616,8 +616,10 @@ __global__ __launch_bounds__(64 * NW) void k_hollow_attn_q_mfma(const AttnTrainA
 }
 
 // dK, dV: wave = 32 keys (lane = key), loop over chunks of 32 queries
+// (held to 128 registers = four waves per SIMD: the unconstrained build takes 156 for three waves; the few spilled dwords cost less
+//  than the lost wave -- dQ + dK/dV pair 196 -> 158 us at the maze shape, 408 -> 376 us at the MNIST hollow shape)
 template <int HD, int NW>
-__global__ __launch_bounds__(64 * NW) void k_hollow_attn_kv_mfma(const AttnTrainArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_hollow_attn_kv_mfma(const AttnTrainArgs a) {
   constexpr int KS = HD / 16, RLD = HD + RLD16;
   __shared__ __attribute__((aligned(16))) unsigned short Qr[32 * RLD], Dr[32 * RLD];     // scale Q rows, dO rows  [query][dim]
   __shared__ __attribute__((aligned(16))) unsigned short Qt[32 * TLD], Dt[32 * TLD];     // their transposes [dim][query]

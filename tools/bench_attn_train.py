@@ -5,9 +5,9 @@ sys.path[:0] = [_R, os.path.join(_R, 'continuous-time-diffusion-models-for-discr
 import torch
 from bench_kernels import timeit
 from ctdd import hollow_train as ht
-D, H, hd = 225, 8, 16
+D, H, hd = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (225, 8, 16)
 E = H * hd
-for B in (4, 16, 32, 64, 128, 256):
+for B in ((int(sys.argv[4]),) if len(sys.argv) > 4 else (4, 16, 32, 64, 128, 256)):
     for p in (0.0, 0.1):
         qkv = torch.randn((B * D, 3 * E), device="cuda")
         rng = torch.tensor([5, 9], dtype=torch.int64, device="cuda")
