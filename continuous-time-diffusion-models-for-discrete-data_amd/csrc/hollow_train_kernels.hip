@@ -480,7 +480,7 @@ __device__ inline bf16x8t tfrag(const unsigned short* T, int col, int kh, int s_
 
 // MODE_BWD false: forward with dropout, writes out (+ bf16 copy) and the row statistics;  true: D_i = dO.O and dQ
 template <int HD, bool BWD, int NW>      // NW waves = 32 NW queries per workgroup
-__global__ __launch_bounds__(64 * NW) void k_hollow_attn_q_mfma(const AttnTrainArgs a) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_hollow_attn_q_mfma(const AttnTrainArgs a) {
   constexpr int KS = HD / 16, RLD = HD + RLD16;
   __shared__ __attribute__((aligned(16))) unsigned short Kr[32 * RLD];          // K rows [key][dim]
   __shared__ __attribute__((aligned(16))) unsigned short Vr[BWD ? 32 * RLD : 8];   // V rows (backward: dP^T = V dO^T)
