@@ -133,6 +133,9 @@ def main():
                     tabs = native.S256Tables(qt0, pr.base_rate, eps)
                     rec("tauleap_step ctelbo (k_tauleap_s256)",
                         timeit(lambda: native.tauleap_step_s256(logits, x, tabs, 0, beta, h, 1, seed, 0, out=out), reps), scan, contraction)
+                    tabb = native.S256Tables(qt0, pr.base_rate, eps, bf16=True)     # single bf16 product (the bf16 network's mode)
+                    rec("tauleap_step ctelbo, single bf16 product (k_tauleap_s256_b16)",
+                        timeit(lambda: native.tauleap_step_s256(logits, x, tabb, 0, beta, h, 1, seed, 0, out=out), reps), scan, contraction / 3)
                     tabc = native.S256Tables(qt0, pr.base_rate, 0.0, crm=True)
                     rec("tauleap_step crm/reverse_prob (k_tauleap_s256)",
                         timeit(lambda: native.tauleap_step_s256(logits, x, tabc, 0, beta, h, 1, seed, 0, out=out), reps), scan, contraction)

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "draw.hpp"
+#include "steps_s256.hpp"
 
 namespace ctdd {
 
@@ -38,10 +39,9 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int S256 = 256;
 constexpr int TILE_ROWS = 128;
-constexpr int CHUNK_BYTES = 16384;          // one K-step (16 s0) of A: [plane 2][g 2][s 256][8 bf16]
-constexpr size_t STEP_TABLE_BYTES = (size_t)S256 * S256 * 4 /*invq*/ + 16 * (size_t)CHUNK_BYTES /*A image*/;
+constexpr int CHUNK_BYTES = S256_CHUNK_BYTES;          // one K-step (16 s0) of A: [plane 2][g 2][s 256][8 bf16]
+constexpr size_t STEP_TABLE_BYTES = S256_STEP_TABLE_BYTES;
 
 // ------------------------------------------------------------------ per-step derived tables
 // invq[x][s0] = 1 / (qt0[s0][x] + eps)                          (fp32, IEEE division)
@@ -60,12 +60,15 @@ __global__ __launch_bounds__(256) void k_step_tables(const float* __restrict__ q
   unsigned char* base = out + (size_t)t * STEP_TABLE_BYTES;
   float* invq = (float*)base;
   unsigned short* img = (unsigned short*)(base + (size_t)S256 * S256 * 4);
+  unsigned short* invq16 = (unsigned short*)(base + S256_INVQ16_OFFSET);      // the same table in bf16 (single-product kernel)
   // each workgroup handles 16 s0 rows (one K-chunk): threads = s
   const int kk = blockIdx.x, s = threadIdx.x;
   for (int r = 0; r < 16; ++r) {
     const int s0 = 16 * kk + r;
     const float v = q[(size_t)s0 * S256 + s];
-    invq[(size_t)s * S256 + s0] = crm ? 1.0f : 1.0f / (v + eps);   // transposed write (x = s here); CRM branch: plain p0t @ qt0
+    const float iq = crm ? 1.0f : 1.0f / (v + eps);                 // CRM branch: plain p0t @ qt0
+    invq[(size_t)s * S256 + s0] = iq;                               // transposed write (x = s here)
+    invq16[(size_t)s * S256 + s0] = bf16_rne(iq);
     const unsigned short hi = bf16_rne(v);
     const unsigned short lo = bf16_rne(v - bf16_to_f32(hi));
     const int g = r >> 3, j = r & 7;
@@ -84,21 +87,6 @@ __global__ void k_rate_views(const float* __restrict__ R, int S, float* __restri
   }
 }
 
-struct S256Args {
-  const float* logits;
-  const int32_t* x;
-  const int32_t* x_base;
-  const unsigned char* tables;   // this step's derived tables (STEP_TABLE_BYTES)
-  const float* RT0;
-  const float* R0;
-  float beta, h;
-  uint32_t flags;
-  uint64_t seed, offset;
-  int64_t R;                     // number of rows N*D
-  float* out_rates;              // optional (R,256): masked reverse rates (validation / unfused use)
-  int32_t* out_x;
-  int32_t* out_changed;
-};
 
 // ---- wave-wide reductions of FOUR independent values at once, entirely on DPP: the four chains
 // are interleaved so every DPP read sits >= 3 instructions behind the write it depends on (the
@@ -527,6 +515,7 @@ extern "C" int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, con
   a.RT0 = (flags & CTDD_STEP_CRM) ? R0 : RT0;      // CRM branch: forward rate out of x, R[x][s]
   a.R0 = R0; a.beta = beta; a.h = h; a.flags = flags; a.seed = seed; a.offset = offset;
   a.R = (int64_t)N * D; a.out_rates = out_rates; a.out_x = out_x; a.out_changed = out_changed;
+  if (flags & CTDD_STEP_BF16) return launch_tauleap_s256_b16(a, (hipStream_t)stream);
   const int64_t grid = (a.R + TILE_ROWS - 1) / TILE_ROWS;
   CTDD_REQUIRE(grid < (1ll << 31), CTDD_ERANGE, "too many rows");
   static bool attr_done[16] = {};

@@ -16,7 +16,7 @@ _LIB = None
 
 BRANCH_CTELBO, BRANCH_CRM = 0, 1
 LOGIT_TYPES = {"direct": 0, "reverse_prob": 1, "reverse_logscale": 2}
-STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM, STEP_COUNT_JUMPS = 1, 2, 4, 8, 16
+STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM, STEP_COUNT_JUMPS, STEP_BF16 = 1, 2, 4, 8, 16, 32
 
 
 class CtddError(RuntimeError):
@@ -421,9 +421,12 @@ class S256Tables:
     """Derived tables for the MFMA tau-leaping kernel: per-step blocks (resident for the whole
     time grid) + the two per-model base-rate views."""
 
-    def __init__(self, qt0, base_rate, eps, crm=False):
-        """crm: tables of the CRM branch with logit_type reverse_prob (unit left scaling; step calls carry STEP_CRM)."""
+    def __init__(self, qt0, base_rate, eps, crm=False, bf16=False):
+        """crm: tables of the CRM branch with logit_type reverse_prob (unit left scaling; step calls carry STEP_CRM).
+        bf16: step calls carry STEP_BF16 -- one bf16 product for the S x S contraction (csrc/steps_s256_b16.hip; the mode of
+        the bf16 score network, relative rate error <= 3 * 2^-8) instead of the three split-bf16 products of the parity mode."""
         self.crm = bool(crm)
+        self.bf16 = bool(bf16)
         nT, S, _ = qt0.shape
         if S != 256:
             raise CtddError("S256Tables needs S == 256")
@@ -454,7 +457,7 @@ def tauleap_step_s256(logits, x, tables, i, beta, h, flags, seed, offset, x_base
         out = torch.empty((N, D), dtype=i32, device=x.device)
     rc = load().ctdd_tauleap_step_s256(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"),
                                        tables.step_ptr(i), _ptr(tables.RT0), _ptr(tables.R0), float(beta), float(h),
-                                       int(flags) | (STEP_CRM if tables.crm else 0), seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
+                                       int(flags) | (STEP_CRM if tables.crm else 0) | (STEP_BF16 if tables.bf16 else 0), seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
                                        _ptr(changed, i32, "changed"), _stream())
     _check(rc, "ctdd_tauleap_step_s256")
     return (out, rates) if want_rates else out

@@ -102,11 +102,25 @@ class _GridSampler:
         """S = 256, CT-ELBO branch or CRM branch with reverse_prob logits: derived tables for the MFMA kernel (csrc/steps_s256.hip)."""
         if self.S != 256 or qt0 is None or not getattr(self.cfg.sampler, "fast_s256", True):
             return None
+        bf16 = self._step_bf16(model)
         if self.branch == native.BRANCH_CTELBO:
-            return native.S256Tables(qt0, model.process.base_rate, self.eps_ratio)
+            return native.S256Tables(qt0, model.process.base_rate, self.eps_ratio, bf16=bf16)
         if self.logit_type == "reverse_prob":                    # CRM branch: the same contraction with a unit left scaling
-            return native.S256Tables(qt0, model.process.base_rate, 0.0, crm=True)
+            return native.S256Tables(qt0, model.process.base_rate, 0.0, crm=True, bf16=bf16)
         return None
+
+    def _step_bf16(self, model):
+        """cfg.sampler.step_precision: "bf16" = one bf16 product for the S x S ratio contraction (relative rate error <= 3 * 2^-8),
+        "fp32" = three split-bf16 products (<= 3e-5, the parity mode), "auto" (default) = bf16 exactly when the score network
+        itself runs single bf16 operands (cfg.model.engine == "hip" with engine_precision "bf16": its logits carry ~1e-2)."""
+        mode = getattr(self.cfg.sampler, "step_precision", "auto")
+        if mode == "auto":
+            m = self.cfg.model
+            default = "bf16" if hasattr(model, "data_shape") else "bf16x3"     # U-Net engine / hollow engine defaults
+            return getattr(m, "engine", "hip") == "hip" and getattr(m, "engine_precision", default) == "bf16"
+        if mode not in ("bf16", "fp32"):
+            raise ValueError(f"sampler.step_precision must be 'auto', 'bf16' or 'fp32', got {mode!r}")
+        return mode == "bf16"
 
     def _leap(self, model, logits, x, q_i, fast, i, beta, h, flags, key, offset, x_base=None, changed=None):
         """One fused reverse-rate / jump / update launch (MFMA path when prepared, else generic)."""

@@ -50,6 +50,9 @@ extern "C" {
                                     (MidPointTauL's change_jump = [2]/[1], sampling.py:489-495) */
 #define CTDD_STEP_CRM 8u         /* ctdd_tauleap_step_s256 only: CRM-branch rates with logit_type reverse_prob (sampling.py:61-73);
                                   * the step tables must come from ctdd_s256_prepare_crm */
+#define CTDD_STEP_BF16 32u       /* ctdd_tauleap_step_s256 only: ONE bf16 product for the S x S contraction (the mode the bf16 score
+                                  * network runs with; all terms are >= 0, relative rate error <= 3 * 2^-8) instead of the three
+                                  * split-bf16 products of the fp32 parity mode.  Same tables, same draw rule. */
 
 int ctdd_abi_version(void);
 const char* ctdd_last_error(void);

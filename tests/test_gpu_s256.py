@@ -207,3 +207,155 @@ def test_lbjf_and_midpoint_on_matrix_core_rates(env, branch):
     diff = (xp != xr)
     assert diff.float().mean().item() < 5e-3 and (xp - xr).abs().max().item() <= 1    # rounding of a drift that sits on .5
     assert (xp != dx).float().mean().item() > 0.05
+
+
+# ---------------------------------------------------------------- single-product bf16 mode (csrc/steps_s256_b16.hip)
+# Tolerance of the mode: 1/(q+eps), w = e^{l-max}/(q+eps) and q_{t|0} are each rounded to bf16 once (unit roundoff 2^-8) and
+# every term of the contraction is >= 0, so a rate is within 3 * 2^-8 = 1.2e-2 of the exact one (observed maximum ~8e-3, rms
+# ~2e-3); the bound asserted is 3 * 2^-8.
+B16_RTOL = 3 * 2.0 ** -8
+
+
+@pytest.mark.parametrize("t,scale,N,D", [(0.5, 1.0, 3, 100), (0.05, 4.0, 2, 131), (0.97, 2.0, 1, 784), (0.3, 8.0, 5, 64)])
+def test_b16_rates_match_oracle(env, t, scale, N, D):
+    native, pr, op = env
+    logits, x = _case(N, D, 1, scale)
+    tt = torch.tensor([t])
+    qt0 = op.transition(tt).cuda()
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9, bf16=True)
+    beta = float(pr.beta(tt)[0])
+    _, rates = native.tauleap_step_s256(logits.cuda().contiguous(), x.to(torch.int32).cuda(), tabs, 0, beta, 1e-3, 1, 1, 0,
+                                        want_rates=True)
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    ref = ops.zero_own_state(ops.reverse_rates_ctelbo(logits, x, q, r, 1e-9)[0], x)
+    np.testing.assert_allclose(rates.cpu().numpy(), ref.numpy(), rtol=B16_RTOL, atol=1e-25)
+    # and the three-product kernel on the same inputs: the two modes differ by the bf16 rounding only
+    tabs3 = native.S256Tables(qt0, pr.base_rate, 1e-9)
+    _, rates3 = native.tauleap_step_s256(logits.cuda().contiguous(), x.to(torch.int32).cuda(), tabs3, 0, beta, 1e-3, 1, 1, 0,
+                                         want_rates=True)
+    np.testing.assert_allclose(rates.cpu().numpy(), rates3.cpu().numpy(), rtol=B16_RTOL, atol=1e-25)
+
+
+@pytest.mark.parametrize("flags,crm", [(1, False), (0, False), (3, False), (1, True), (3, True)])
+def test_b16_fused_step_replays_from_its_own_rates(env, flags, crm):
+    """The draw of the bf16 kernel replayed on the CPU (oracle/philox.py) from the rates the same kernel reports: same Philox
+    stream, same rule.  The in-group cumulative offsets are parked in LDS as bf16, so a pick within 2^-9 of a boundary may land
+    on the neighbouring destination: the mismatch bar is 2e-2 of the decided rows (the parity kernel: 3e-3)."""
+    native, pr, op = env
+    N, D = 4, 300
+    logits, x = _case(N, D, 5 + int(crm), 2.0)
+    tt = torch.tensor([0.4])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = (ops.reverse_rates_crm("reverse_prob", logits, x, q, r) if crm else ops.reverse_rates_ctelbo(logits, x, q, r, 1e-9))[0]
+    if flags & 2:
+        rr = rr + ops.transpose_forward_rates(r, x)
+    h = float(1.0 / ops.zero_own_state(rr, x).sum(-1).median())
+    tabs = native.S256Tables(qt0, pr.base_rate, 0.0 if crm else 1e-9, crm=crm, bf16=True)
+    dl, dx = logits.cuda().contiguous(), x.to(torch.int32).cuda()
+    changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 77, 3, changed=changed).cpu().long()
+    _, rates = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 77, 3, want_rates=True, want_x=False)
+    np.testing.assert_allclose(rates.cpu().numpy(), ops.zero_own_state(rr, x).numpy(), rtol=B16_RTOL, atol=1e-25)
+    ref, decided = oph.tauleap_draw_replay(rates.cpu().numpy(), x.numpy(), h, bool(flags & 1), 77, 3)
+    dec = torch.from_numpy(decided)
+    assert dec.float().mean() > 0.6
+    assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 2e-2
+    assert int(changed.item()) == int((out != x).sum())
+    assert (out != x).float().mean() > 0.05
+    # same stream as the parity kernel: the two modes decide alike except where the 2^-8 rate difference flips a comparison
+    tabs3 = native.S256Tables(qt0, pr.base_rate, 0.0 if crm else 1e-9, crm=crm)
+    out3 = native.tauleap_step_s256(dl, dx, tabs3, 0, beta, h, flags, 77, 3).cpu().long()
+    assert (out != out3).float().mean().item() < 3e-2
+
+
+def test_b16_dense_rows_and_mixed_regimes(env):
+    """A step size that puts rows on both sides of Lambda = 64 (superposition / dense sub-block draw) in the same waves.
+    Dense rows replay exactly up to float near-ties.  Rows just below 64 draw 30-60 destinations each; every one of them
+    is resolved inside its group of 8 from bf16 offsets (2^-8), so the SUM of the moves may differ from the fp32 replay by a
+    destination or two: there the test bounds the size of the difference, not its frequency."""
+    native, pr, op = env
+    N, D = 2, 200
+    logits, x = _case(N, D, 31, 2.0)
+    tt = torch.tensor([0.8])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = ops.reverse_rates_ctelbo(logits, x, q, r, 1e-9)[0]
+    tot = ops.zero_own_state(rr, x).sum(-1)
+    h = float(64.0 / tot.median())                       # half the rows above 64, half below
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9, bf16=True)
+    dl, dx = logits.cuda().contiguous(), x.to(torch.int32).cuda()
+    for flags in (1, 0):
+        out = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 5, 9).cpu().long()
+        _, rates = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, flags, 5, 9, want_rates=True, want_x=False)
+        lam = rates.cpu().sum(-1) * h
+        is_dense = lam > 64
+        assert 0.2 < is_dense.float().mean() < 0.8
+        ref, decided = oph.tauleap_draw_replay(rates.cpu().numpy(), x.numpy(), h, bool(flags & 1), 5, 9)
+        ref, dec = torch.from_numpy(ref), torch.from_numpy(decided)
+        assert dec.float().mean() > 0.5
+        assert (out[dec & is_dense] != ref[dec & is_dense]).float().mean().item() < 2e-2
+        sp = dec & ~is_dense
+        assert (out[sp] - ref[sp]).abs().max().item() <= 3 and (out[sp] - ref[sp]).abs().float().mean().item() < 0.5
+        assert int(out.min()) >= 0 and int(out.max()) <= S - 1
+
+
+def test_b16_midpoint_base_and_ragged_tail(env):
+    native, pr, op = env
+    N, D = 1, 131
+    logits, x = _case(N, D, 9, 2.0)
+    xb = (x + torch.randint(-3, 4, x.shape)).clamp(0, S - 1)
+    tt = torch.tensor([0.6])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9, bf16=True)
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    rr = ops.reverse_rates_ctelbo(logits, xb, q, r, 1e-9)[0]
+    h = float(1.0 / ops.zero_own_state(rr, xb).sum(-1).median())
+    dl, dx, dxb = logits.cuda().contiguous(), x.to(torch.int32).cuda(), xb.to(torch.int32).cuda()
+    out = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, 0, 5, 1, x_base=dxb).cpu().long()
+    _, rates = native.tauleap_step_s256(dl, dx, tabs, 0, beta, h, 0, 5, 1, x_base=dxb, want_rates=True, want_x=False)
+    np.testing.assert_allclose(rates.cpu().numpy(), ops.zero_own_state(rr, xb).numpy(), rtol=B16_RTOL, atol=1e-25)
+    ref, decided = oph.tauleap_draw_replay(rates.cpu().numpy(), x.numpy(), h, False, 5, 1, x_base=xb.numpy())
+    dec = torch.from_numpy(decided)
+    assert (out[dec] != torch.from_numpy(ref)[dec]).float().mean().item() < 2e-2 and dec.float().mean() > 0.5
+
+
+def test_b16_full_size_properties_and_jump_law(env):
+    """BASELINE size (N=256, D=784): determinism, stream separation, h = 0, range, change counter -- and the law of the move:
+    the mean and the variance of the ordinal jump per dimension against the rates' own first two moments
+    (E J = h sum_s r_s (s - x), Var J = h sum_s r_s (s - x)^2 for independent Poisson counts), over 200 704 dimensions."""
+    native, pr, _ = env
+    N, D = 256, 784
+    g = torch.Generator(device="cuda").manual_seed(3)
+    logits = torch.randn((N, D, S), generator=g, device="cuda") * 2.0
+    x = torch.randint(40, S - 40, (N, D), generator=g, device="cuda", dtype=torch.int32)
+    tt = torch.tensor([0.4])
+    tabs = native.S256Tables(pr.transition(tt), pr.base_rate, 1e-9, bf16=True)
+    beta = float(pr.beta(tt)[0])
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    h = 2e-3
+    a = native.tauleap_step_s256(logits, x, tabs, 0, beta, h, native.STEP_ORDINAL, 7, 11, changed=cnt)
+    b = native.tauleap_step_s256(logits, x, tabs, 0, beta, h, native.STEP_ORDINAL, 7, 11)
+    c = native.tauleap_step_s256(logits, x, tabs, 0, beta, h, native.STEP_ORDINAL, 7, 12)
+    z = native.tauleap_step_s256(logits, x, tabs, 0, beta, 0.0, native.STEP_ORDINAL, 7, 11)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.equal(z, x)
+    assert int(a.min()) >= 0 and int(a.max()) <= S - 1
+    moved = int((a != x).sum())
+    assert int(cnt.item()) == moved and 0 < moved < N * D
+    d = native.tauleap_step_s256(logits, x, tabs, 0, beta, h, 0, 7, 11)
+    assert int((d != x).sum()) <= moved
+    _, rates = native.tauleap_step_s256(logits, x, tabs, 0, beta, h, native.STEP_ORDINAL, 7, 11, want_rates=True, want_x=False)
+    sx = (torch.arange(S, device="cuda")[None, None, :] - x[..., None]).double()
+    mean = (rates.double() * sx).sum(-1) * h
+    var = (rates.double() * sx * sx).sum(-1) * h
+    J = (a - x).double()
+    inner = (a > 0) & (a < S - 1)                      # (the clamp at the borders censors the move)
+    assert inner.float().mean() > 0.99
+    n = float(inner.sum())
+    zscore = float(((J - mean)[inner]).sum() / var[inner].sum().sqrt())
+    assert abs(zscore) < 5.0, zscore
+    ratio = float(((J - mean)[inner] ** 2).sum() / var[inner].sum())
+    assert abs(ratio - 1.0) < 0.05, ratio
