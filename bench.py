@@ -11,10 +11,12 @@ weights) are resident in HBM before the timed region.  Sampling shards over GPUs
 data-path collective: weak scaling, value = all ranks' sample-steps / max-rank time.
 
 The JSON line also carries
-  roofline          the fused tau-leap kernel k_tauleap_s256: algorithmic bytes per sample-step
-                    (809 088 B at fp32) x batch / its mean launch duration (HIP events on
-                    the launch stream); `mfma_view` prices the same launches by their matrix FLOPs
-                    (3 split-bf16 products of the D x S x S contraction);
+  roofline          the fused tau-leap kernel (k_tauleap_s256_b16 in the bf16 mode the headline runs: one bf16 product,
+                    bf16 logits straight from the output convolution; k_tauleap_s256 in the fp32 parity mode):
+                    algorithmic bytes per sample-step (407 680 B with bf16 logits, 809 088 B with fp32
+                    logits) x batch / its mean launch duration (HIP events on the launch stream); `mfma_view` prices
+                    the same launches by their matrix FLOPs; `fp32_logit_equivalent_frac` is the same duration priced
+                    with the fp32-logit byte count rounds 1 and 2 reported;
   roofline_network  the score-network forward (the larger share of the step): 2 M N K matrix FLOPs of its convolutions /
                     the forward's wall time as it runs in the loop (graph replay, two sub-batches on parallel streams, GroupNorm
                     etc. included) vs the dense bf16 MFMA peak; the convolution launches replayed one by one are reported too;
@@ -39,6 +41,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 (no sparsity)
 D, S = 784, 256
 ALGO_BYTES_PER_SAMPLE_STEP = D * S * 4 + D * 4 + D * 4      # fp32 logits + x in + x out
+ALGO_BYTES_PER_SAMPLE_STEP_BF16 = D * S * 2 + D * 4 + D * 4  # bf16 logits + x in + x out
 
 
 def parse():
@@ -73,49 +76,62 @@ def build_model(device):
 
 def kernel_roofline(sampler, st, steps, batch, restore_state=False):
     """Mean duration of the fused tau-leap launch alone, HIP events on the launch stream, over the
-    same steps (logits recomputed outside the event bracket)."""
-    from ctdd import native
+    same steps (logits recomputed outside the event bracket, exactly as the sampler loop gets them)."""
     model = st.model
     times = []
     x_keep = st.x
-    for i in steps:
-        t_ones = sampler._t_ones(st.t32, i, st.N, st.dev)
-        logits = model(st.x.long(), t_ones).float().contiguous()
-        h = float(np.float32(st.ts[i] - st.ts[i + 1]))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        st.x = sampler._leap(model, logits, st.x, st.qt0[i], st.fast, i, st.betas[i], h, st.flags, st.key,
-                             10_000_000 + i)
-        e1.record()
-        e1.synchronize()
-        times.append(e0.elapsed_time(e1) * 1e-3)
+    l16 = False
+    with sampler._borrow(model):
+        for i in steps:
+            t_ones = sampler._t_ones(st.t32, i, st.N, st.dev)
+            logits = sampler._net_logits(model, st.x, t_ones, st.fast)
+            l16 = logits.dtype == torch.bfloat16
+            h = float(np.float32(st.ts[i] - st.ts[i + 1]))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st.x = sampler._leap(model, logits, st.x, st.qt0[i], st.fast, i, st.betas[i], h, st.flags, st.key,
+                                 10_000_000 + i)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e-3)
     dur = float(np.mean(times))
     if restore_state:
         st.x = x_keep
+    bf16_step = st.fast is not None and st.fast.bf16
+    per = ALGO_BYTES_PER_SAMPLE_STEP_BF16 if l16 else ALGO_BYTES_PER_SAMPLE_STEP
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_tauleap_s256.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic_tauleap_s256_b16.json" if bf16_step else "r01_pmc_traffic_tauleap_s256.json")
     if batch == 256 and os.path.exists(pmc):          # HBM bytes per launch from the committed rocprofv3 --pmc passes (same workload)
         with open(pmc) as f:
             rec = json.load(f)
-        traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic_tauleap_s256.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
-    achieved = ALGO_BYTES_PER_SAMPLE_STEP * batch / dur / 1e9
-    mfma_flops = 3 * 2 * D * S * S * batch                     # hi*hi + hi*lo + lo*hi products of the S x S contraction
-    return {"kernel": "ctdd k_tauleap_s256 (fused softmax + split-bf16 MFMA contraction + Poisson draw + update)", "bound": "hbm", "achieved": round(achieved, 2),
+        traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.relpath(pmc, ROOT) + " (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    achieved = per * batch / dur / 1e9
+    nprod = 1 if bf16_step else 3                               # bf16 mode: one product; parity mode: hi*hi + hi*lo + lo*hi
+    mfma_flops = nprod * 2 * D * S * S * batch
+    kernel = ("ctdd k_tauleap_s256_b16 (LDS-DMA rows -> softmax in MFMA fragment order -> one bf16 MFMA contraction -> rates -> Poisson draw + update; "
+              + ("bf16" if l16 else "fp32") + " logits)") if bf16_step else \
+        "ctdd k_tauleap_s256 (fused softmax + split-bf16 MFMA contraction + Poisson draw + update)"
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE_STEP * batch,
+            "avg_launch_us": round(dur * 1e6, 2), "algorithmic_bytes_per_launch": per * batch, "logits_dtype": "bf16" if l16 else "f32",
+            "fp32_logit_equivalent_frac": round(ALGO_BYTES_PER_SAMPLE_STEP * batch / dur / 1e9 / HBM_PEAK_GBS, 5),
             "mfma_view": {"achieved": round(mfma_flops / dur / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(mfma_flops / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}}
+                          "frac": round(mfma_flops / dur / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5), "products": nprod}}
 
 
-def network_roofline(model, batch):
+def network_roofline(model, batch, sampler=None):
     """The U-Net engine's convolution launches replayed one by one (eager, outside the HIP graph) with HIP
     events on the launch stream: summed 2*M*N*K matrix FLOPs / summed durations."""
     eng = getattr(model, "_engine", None)
     if eng is None:
         return None
     plans = []
+    want_lb = None
+    if sampler is not None:                                          # the plans the sampler loop replays (bf16 or fp32 logits)
+        with sampler._borrow(model):
+            want_lb = bool(getattr(model, "_engine_logits_bf16", False))
     for key, st in eng._plans.items():
-        if key[0] != batch:
+        if key[0] != batch or (want_lb is not None and key[-1] != want_lb):
             continue
         plans.extend(st[1] if isinstance(st, tuple) else [st])       # (logits, sub-plans, streams) when the batch runs as sub-batches
     if not plans:
@@ -142,7 +158,7 @@ def network_roofline(model, batch):
     x = torch.randint(0, S, (batch, D), device=next(model.parameters()).device)
     t = torch.full((batch,), 0.5, device=x.device)
     from lib.models.models import borrow_engine_output
-    with borrow_engine_output(model):          # as the sampler loop calls it: the plan's own output buffer, no copy
+    with (sampler._borrow(model) if sampler is not None else borrow_engine_output(model)):   # as the sampler loop calls it: the plan's own output buffer, no copy
         model(x, t)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -346,7 +362,7 @@ def main():
         # the same kernel mid-trajectory (t ~ 0.5: fewer dimensions jump than next to t = 1, where the timed steps run)
         mid = sampler.num_steps // 2
         roof_mid = kernel_roofline(sampler, st, range(mid, mid + 20), a.batch, restore_state=True) if rank == 0 else None
-        roof_net = network_roofline(model, a.batch) if rank == 0 else None
+        roof_net = network_roofline(model, a.batch, sampler) if rank == 0 else None
         fp32_mode = fp32_parity_mode(cfg, model, sampler, a.batch) if (rank == 0 and world == 1 and not a.no_fp32_mode) else None
     if rank == 0:
         value = a.batch * K * world / el
@@ -354,14 +370,14 @@ def main():
             "metric": "tau-leaping sample-steps/s", "value": round(value, 2), "unit": "sample-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "dtype_detail": "bf16 score network (fp32 accumulate) + f32 rates/softmax with split-bf16 MFMA contraction", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
+            "dtype": "bf16", "dtype_detail": "bf16 score network (fp32 accumulate, bf16 logits) + tau-leap step with f32 softmax / rates and ONE bf16 MFMA product for the S x S ratio contraction (relative rate error <= 3 * 2^-8; the three-product f32-parity step is timed in fp32_parity_mode)", "data": "synthetic (random-init weights, Gaussian initial state, resident in HBM)",
             "config": {"workload": "MNIST tauLDR U-Net TauL step (config_tauUnet_mnist: D=784, S=256, 1000-step grid)",
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "D": D, "S": S,
                        "parallelism": f"sample-sharded x{world}, no collective in the loop"},
             "dims_per_s": round(value * D, 1),
             "roofline": roof,
             "roofline_network": roof_net,
-            "roofline_mid_trajectory": None if roof_mid is None else {k_: roof_mid[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "mfma_view")},
+            "roofline_mid_trajectory": None if roof_mid is None else {k_: roof_mid[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "fp32_logit_equivalent_frac", "mfma_view")},
             "fp32_parity_mode": fp32_mode,
         }
         if world == 1 and not a.no_train_step:

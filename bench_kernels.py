@@ -136,6 +136,11 @@ def main():
                     tabb = native.S256Tables(qt0, pr.base_rate, eps, bf16=True)     # single bf16 product (the bf16 network's mode)
                     rec("tauleap_step ctelbo, single bf16 product (k_tauleap_s256_b16)",
                         timeit(lambda: native.tauleap_step_s256(logits, x, tabb, 0, beta, h, 1, seed, 0, out=out), reps), scan, contraction / 3)
+                    lg16 = logits.to(torch.bfloat16)
+                    scan16 = B * (D * S * 2 + 8 * D)                     # SURVEY 8d's bf16 figure: 407 680 B per MNIST sample-step
+                    rec("tauleap_step ctelbo, single bf16 product, bf16 logits (k_tauleap_s256_b16)",
+                        timeit(lambda: native.tauleap_step_s256(lg16, x, tabb, 0, beta, h, 1, seed, 0, out=out), reps), scan16, contraction / 3)
+                    del lg16
                     tabc = native.S256Tables(qt0, pr.base_rate, 0.0, crm=True)
                     rec("tauleap_step crm/reverse_prob (k_tauleap_s256)",
                         timeit(lambda: native.tauleap_step_s256(logits, x, tabc, 0, beta, h, 1, seed, 0, out=out), reps), scan, contraction)

@@ -503,15 +503,16 @@ static int s256_prepare(const float* qt0, const float* base_rate, float eps, int
   return CTDD_OK;
 }
 
-extern "C" int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, const int32_t* x_base,
+extern "C" int ctdd_tauleap_step_s256(const void* logits, const int32_t* x, const int32_t* x_base,
                                       const void* step_tables, const float* RT0, const float* R0, float beta,
                                       float h, uint32_t flags, uint64_t seed, uint64_t offset, int N, int D,
                                       float* out_rates, int32_t* out_x, int32_t* out_changed, void* stream) {
   CTDD_REQUIRE(logits && x && step_tables && RT0 && R0, CTDD_EINVAL, "null input");
   CTDD_REQUIRE(out_x || out_rates, CTDD_EINVAL, "no output requested");
   CTDD_REQUIRE(N > 0 && D > 0, CTDD_EINVAL, "N=%d D=%d must be positive", N, D);
+  CTDD_REQUIRE(!(flags & CTDD_STEP_LOGITS_BF16) || (flags & CTDD_STEP_BF16), CTDD_EINVAL, "bf16 logits need CTDD_STEP_BF16");
   S256Args a{};
-  a.logits = logits; a.x = x; a.x_base = x_base; a.tables = (const unsigned char*)step_tables;
+  a.logits = (const float*)logits; a.x = x; a.x_base = x_base; a.tables = (const unsigned char*)step_tables;
   a.RT0 = (flags & CTDD_STEP_CRM) ? R0 : RT0;      // CRM branch: forward rate out of x, R[x][s]
   a.R0 = R0; a.beta = beta; a.h = h; a.flags = flags; a.seed = seed; a.offset = offset;
   a.R = (int64_t)N * D; a.out_rates = out_rates; a.out_x = out_x; a.out_changed = out_changed;

@@ -67,11 +67,14 @@ __host__ __device__ constexpr int mid_wait(int c) { return c == 0 ? 12 : c <= 4 
 
 // GENERAL = false: the sampler's plain step (no corrector term, no CRM normaliser, no rate output, no x_base): the same
 // code with those uniform branches compiled out, so the epilogue is straight-line.
-template <bool GENERAL>
+// L16 = true: the logits are bf16 (the bf16 network's output convolution writes them that way: half the bytes of the
+// step's one large read); both passes then fit the staging buffer and come in by LDS-DMA.
+template <bool GENERAL, bool L16>
 __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef CTDD_S256_STAMPS
   unsigned long long stamps[6];
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #endif
   B16_STAMP(0)
   const int lane = threadIdx.x & 63;
@@ -109,6 +112,70 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
   constexpr float LOG2E = 1.4426950408889634f;
   u32x4 bw[16];                        // B fragments: bw[kk] = w[row j][16 kk + 8 g .. + 7] as 8 bf16 (after the lane swap)
   float zv = 1.0f;                     // Z of row (lane & 31)
+  const unsigned short* invq16 = (const unsigned short*)(a.tables + S256_INVQ16_OFFSET);
+  if constexpr (L16) {
+    // 32 rows x 512 B: sixteen DMA instructions of two rows each; pass p = rows 16p .. 16p+15 at stg + 8192 p, a row's
+    // 32 pieces XOR-swizzled by its number (source side)
+    const unsigned short* lg = (const unsigned short*)a.logits;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 2 * i + (lane >> 5);
+      const int64_t row = wrow0 + r;
+      const int64_t rowc = row < a.R ? row : a.R - 1;
+      const unsigned char* src = (const unsigned char*)(lg + (size_t)rowc * S256) + (((lane & 31) ^ (r & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(stg + i * 1024), 16, 0, 0);
+    }
+    xcur = min(max(xcur, 0), S256 - 1);
+    xj = min(max(xj, 0), S256 - 1);
+    u32x4 iqb[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int xp = __shfl(xj, j16 + 16 * p, WAVE);                 // rate-state of row 16 p + j16
+      const unsigned short* qrow = invq16 + (size_t)xp * S256 + 128 * (q4 & 1) + 8 * (q4 >> 1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) iqb[p][i] = *(const u32x4*)(qrow + 16 * i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // rows, gathers (and chunk 0) have landed
+    B16_STAMP(5)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      u32x4 raw[8];
+      const unsigned char* myrow = stg + p * 8192 + j16 * 512;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int f = 16 * (q4 & 1) + 2 * i + (q4 >> 1);             // fragment piece = 16-byte piece of the bf16 row
+        raw[i] = *(const u32x4*)(myrow + ((f ^ j16) << 4));
+      }
+      float m0 = bf_lo(raw[0][0]), m1 = bf_hi(raw[0][0]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { m0 = fmaxf(m0, bf_lo(raw[i][d])); m1 = fmaxf(m1, bf_hi(raw[i][d])); }
+      float mx = fmaxf(m0, m1);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+      const float ms = mx * LOG2E;
+      float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u32x4 qb = iqb[p][i];
+        u32x4 w;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(bf_lo(raw[i][d]), LOG2E, -ms));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(bf_hi(raw[i][d]), LOG2E, -ms));
+          z0 += e0; z1 += e1;
+          w[d] = pack_bf16(e0 * bf_lo(qb[d]), e1 * bf_hi(qb[d]));
+        }
+        bw[8 * p + i] = w;
+      }
+      float z = z0 + z1;
+      z += __shfl_xor(z, 16, WAVE);
+      z += __shfl_xor(z, 32, WAVE);
+      zv = ((q4 & 1) == p) ? z : zv;                                  // the lane that ends up with row 16 p + j16
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t row = wrow0 + r;
@@ -129,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
   xj = min(max(xj, 0), S256 - 1);
   u32x4 iqb[2][8];                     // (native vector type: a struct-typed array here went to scratch memory)
   {
-    const unsigned short* invq16 = (const unsigned short*)(a.tables + S256_INVQ16_OFFSET);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int xp = __shfl(xj, j16 + 16 * p, WAVE);                 // rate-state of row 16 p + j16
@@ -191,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       w[3] = pack_bf16(e1.z * bf_lo(qb[3]), e1.w * bf_hi(qb[3]));
       bw[8 * p + i] = w;
     }
+  }
   }
   // even 16-lane rows computed K-steps 0..7, odd rows K-steps 8..15; pass 0 sits in bw[0..7], pass 1 in bw[8..15].
   // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second: afterwards lane
@@ -458,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
     o[5] = __builtin_amdgcn_s_memrealtime();
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    o[6] = ((unsigned long long)xcc << 32) | hwid;
+    o[6] = rt0_;   (void)xcc; (void)hwid;
     o[7] = stamps[5];
   }
   return;
@@ -469,14 +536,23 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
     a.out_x[myrow] = xn;
     moved = (a.flags & CTDD_STEP_COUNT_RAW) ? (jump != 0) : (xn != xcur);
   }
-  if (a.out_changed) {                       // one atomic per wave instead of one per row on a single address
+  if (a.out_changed) {
+    // ONE atomic per workgroup and counter: the waves leave their counts in their own (by now idle) LDS regions and wave 0
+    // adds them up behind a barrier.  (One atomic per wave -- 6 272 adds on one address per 256-sample launch, ~12 ns each
+    // at the memory side -- took as long as the rest of the kernel.)
+    const bool cj = a.flags & CTDD_STEP_COUNT_JUMPS;
     const int nmoved = __builtin_popcountll(__ballot(moved));
-    if (lane == 0 && nmoved) atomicAdd(a.out_changed, nmoved);
-    if (a.flags & CTDD_STEP_COUNT_JUMPS) {   // sampling.py:489-495: dimensions with >= 1 and with > 1 jump events
-      const int n1 = __builtin_popcountll(__ballot(live && g == 0 && njumps > 0));
-      const int n2 = __builtin_popcountll(__ballot(live && g == 0 && njumps > 1));
-      if (lane == 0 && n1) atomicAdd(a.out_changed + 1, n1);
-      if (lane == 0 && n2) atomicAdd(a.out_changed + 2, n2);
+    const int n1 = cj ? __builtin_popcountll(__ballot(live && g == 0 && njumps > 0)) : 0;   // sampling.py:489-495: dimensions with
+    const int n2 = cj ? __builtin_popcountll(__ballot(live && g == 0 && njumps > 1)) : 0;   // >= 1 and with > 1 jump events
+    int* slot = (int*)(smem + wave * 16384);
+    if (lane == 0) { slot[0] = nmoved; slot[1] = n1; slot[2] = n2; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x < 3) {
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) tot += ((const int*)(smem + w * 16384))[threadIdx.x];
+      if (tot && (threadIdx.x == 0 || cj)) atomicAdd(a.out_changed + threadIdx.x, tot);
     }
   }
 }
@@ -486,16 +562,17 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
 int launch_tauleap_s256_b16(const S256Args& a, hipStream_t stream) {
   const int64_t grid = (a.R + b16::TILE_ROWS - 1) / b16::TILE_ROWS;
   CTDD_REQUIRE(grid < (1ll << 31), CTDD_ERANGE, "too many rows");
-  static bool attr_done[16] = {};
   const bool general = a.x_base || a.out_rates || (a.flags & (CTDD_STEP_CORRECTOR | CTDD_STEP_CRM));
-  if (general) {
-    ensure_lds_ceiling((const void*)b16::k_tauleap_s256_b16<true>, attr_done);
-    hipLaunchKernelGGL(b16::k_tauleap_s256_b16<true>, dim3((unsigned)grid), dim3(256), b16::LDS_BYTES, stream, a);
-  } else {
-    static bool attr_done_plain[16] = {};
-    ensure_lds_ceiling((const void*)b16::k_tauleap_s256_b16<false>, attr_done_plain);
-    hipLaunchKernelGGL(b16::k_tauleap_s256_b16<false>, dim3((unsigned)grid), dim3(256), b16::LDS_BYTES, stream, a);
-  }
+  const bool l16 = a.flags & CTDD_STEP_LOGITS_BF16;
+  static bool attr_done4[4][16] = {};
+  auto go = [&](auto kernel, int slot) {
+    ensure_lds_ceiling((const void*)kernel, attr_done4[slot]);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), b16::LDS_BYTES, stream, a);
+  };
+  if (general && l16) go(b16::k_tauleap_s256_b16<true, true>, 0);
+  else if (general) go(b16::k_tauleap_s256_b16<true, false>, 1);
+  else if (l16) go(b16::k_tauleap_s256_b16<false, true>, 2);
+  else go(b16::k_tauleap_s256_b16<false, false>, 3);
   return finish_launch("k_tauleap_s256_b16");
 }
 

@@ -135,15 +135,13 @@ __device__ inline void conv_epilogue_tile(const ConvArgs& a, const f32x16& acc, 
       const size_t o = (size_t)p * a.N + n;
       if (a.res_f32) v += a.res_f32[o];
       else if (a.res_bf16) v += from_bf16(a.res_bf16[o]);
-      if (a.out_f32) {
-        if (a.logits_C > 0) {
-          const int b = b_first + (second ? 1 : 0);
-          a.out_f32[(((size_t)b * a.logits_C + lch) * HW + (p - (int64_t)b * HW)) * S + ls] = v;
-        } else {
-          a.out_f32[o] = v;
-        }
+      size_t oo = o;                                       // logits layout (B, C*H*W, S): row = c*HW + p, fp32 and/or bf16
+      if (a.logits_C > 0) {
+        const int b = b_first + (second ? 1 : 0);
+        oo = (((size_t)b * a.logits_C + lch) * HW + (p - (int64_t)b * HW)) * S + ls;
       }
-      if (a.out_hi) a.out_hi[o] = to_bf16(v);
+      if (a.out_f32) a.out_f32[oo] = v;
+      if (a.out_hi) a.out_hi[oo] = to_bf16(v);
       if (second) { s1 += v; q1 += (double)v * v; } else { s0 += v; q0 += (double)v * v; }
     }
   }
@@ -292,18 +290,19 @@ __device__ __attribute__((always_inline)) inline void conv_epilogue_rows(const C
           const float4 r0 = *(const float4*)(p_res_f32 + o), r1 = *(const float4*)(p_res_f32 + o + 4);
           v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
         }
+        size_t oo = o;                                     // logits layout (B, C*H*W, S): row = c*HW + p, fp32 and/or bf16
+        if (a_lc > 0) {
+          const int b = b_first + (second ? 1 : 0);
+          oo = (((size_t)b * a_lc + lch) * HW + (p - (int64_t)b * HW)) * S + ls;
+        }
         if (p_out_f32) {
-          float* dst = p_out_f32 + o;
-          if (a_lc > 0) {
-            const int b = b_first + (second ? 1 : 0);
-            dst = p_out_f32 + (((size_t)b * a_lc + lch) * HW + (p - (int64_t)b * HW)) * S + ls;
-          }
+          float* dst = p_out_f32 + oo;
           *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
           *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
         if (p_out_hi) {
           const uint4 hv = make_uint4(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]), pack2_bf16(v[4], v[5]), pack2_bf16(v[6], v[7]));
-          *(uint4*)(p_out_hi + o) = hv;
+          *(uint4*)(p_out_hi + oo) = hv;
           if (p_out_lo) {
             const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w};
             unsigned lw[4];

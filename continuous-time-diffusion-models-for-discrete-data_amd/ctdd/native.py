@@ -16,7 +16,7 @@ _LIB = None
 
 BRANCH_CTELBO, BRANCH_CRM = 0, 1
 LOGIT_TYPES = {"direct": 0, "reverse_prob": 1, "reverse_logscale": 2}
-STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM, STEP_COUNT_JUMPS, STEP_BF16 = 1, 2, 4, 8, 16, 32
+STEP_ORDINAL, STEP_CORRECTOR, STEP_COUNT_RAW, STEP_CRM, STEP_COUNT_JUMPS, STEP_BF16, STEP_LOGITS_BF16 = 1, 2, 4, 8, 16, 32, 64
 
 
 class CtddError(RuntimeError):
@@ -452,12 +452,17 @@ def tauleap_step_s256(logits, x, tables, i, beta, h, flags, seed, offset, x_base
     N, D, S = logits.shape
     if S != 256:
         raise CtddError("tauleap_step_s256 needs S == 256")
-    rates = torch.empty_like(logits) if want_rates else None
+    rates = torch.empty(logits.shape, dtype=f32, device=logits.device) if want_rates else None
     if want_x and out is None:
         out = torch.empty((N, D), dtype=i32, device=x.device)
-    rc = load().ctdd_tauleap_step_s256(_ptr(logits, f32, "logits"), _ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"),
+    lflag = 0
+    if logits.dtype == torch.bfloat16:                       # bf16 logits (the bf16 U-Net engine's output): bf16 step only
+        if not tables.bf16:
+            raise CtddError("tauleap_step_s256: bf16 logits need S256Tables(..., bf16=True)")
+        lflag = STEP_LOGITS_BF16
+    rc = load().ctdd_tauleap_step_s256(_ptr(logits, torch.bfloat16 if lflag else f32, "logits"), _ptr(x, i32, "x"), _ptr(x_base, i32, "x_base"),
                                        tables.step_ptr(i), _ptr(tables.RT0), _ptr(tables.R0), float(beta), float(h),
-                                       int(flags) | (STEP_CRM if tables.crm else 0) | (STEP_BF16 if tables.bf16 else 0), seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
+                                       int(flags) | (STEP_CRM if tables.crm else 0) | (STEP_BF16 if tables.bf16 else 0) | lflag, seed, offset, N, D, _ptr(rates), _ptr(out, i32, "out") if want_x else None,
                                        _ptr(changed, i32, "changed"), _stream())
     _check(rc, "ctdd_tauleap_step_s256")
     return (out, rates) if want_rates else out

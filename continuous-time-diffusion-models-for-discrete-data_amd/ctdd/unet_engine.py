@@ -164,7 +164,7 @@ class UNetEngine:
         self._stats_off += n
         return off
 
-    def _build(self, B, x_dtype, logits_out=None, tc=None):
+    def _build(self, B, x_dtype, logits_out=None, tc=None, logits_bf16=False):
         net, m = self.net, self.cfg.model
         lib = _lib()
         dev = self.dev
@@ -245,7 +245,10 @@ class UNetEngine:
                 else:
                     a.res_bf16 = ptr(res.hi)
             if out_f32_tensor is not None:
-                a.out_f32 = ptr(out_f32_tensor)
+                if out_f32_tensor.dtype == torch.bfloat16:      # (the bf16 logits of the sampler loops)
+                    a.out_hi = ptr(out_f32_tensor)
+                else:
+                    a.out_f32 = ptr(out_f32_tensor)
             elif out is not None:
                 a.out_f32, a.out_hi = ptr(out.f32), ptr(out.hi)
                 if out.stats is not None:
@@ -497,7 +500,9 @@ class UNetEngine:
             if tc is None:                             # (training: the head runs as differentiable device ops on net_out)
                 launch(lib.ctdd_unet_logistic_head, C.byref(la))
         else:
-            st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=torch.float32, device=dev)
+            ldt = torch.bfloat16 if logits_bf16 else torch.float32
+            st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=ldt, device=dev)
+            assert st.logits.dtype == ldt
             conv([(ao, ao.C, SEG_3x3)], [(oc.weight, 0)],
                  oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.logits,
                  logits_C=Cin, bias_params=[oc.bias])
@@ -530,9 +535,9 @@ class UNetEngine:
         for step in st.plan:
             step()
 
-    def _prepare(self, B, x_dtype, x, times, logits_out=None):
+    def _prepare(self, B, x_dtype, x, times, logits_out=None, logits_bf16=False):
         """Build, warm up and capture the plan for (B, dtype)."""
-        st = self._build(B, x_dtype, logits_out)
+        st = self._build(B, x_dtype, logits_out, logits_bf16=logits_bf16)
         st.x_in.copy_(x.reshape(st.x_in.shape))
         st.t_in.copy_(times.float())
         self._run_plan(st)                    # eager warm-up (also sets the LDS attributes)
@@ -563,8 +568,10 @@ class UNetEngine:
                 pass
             raise native.CtddError("eager replay goes through _run_plan")
 
-    def __call__(self, x, times):
+    def __call__(self, x, times, logits_bf16=False):
+        """logits_bf16: write the (B, D, S) logits in bf16 (bf16 engine with the `logits` head; ignored otherwise)."""
         B = x.shape[0]
+        lb = bool(logits_bf16) and not self.precise and self.cfg.model.model_output == "logits"
         ver = self._weights_version()
         if ver != self._wver:                     # weights changed (optimizer step, EMA swap): re-pack
             self._plans.clear()
@@ -575,15 +582,15 @@ class UNetEngine:
         # CUs that one forward leaves idle (half-empty last rounds of the 392-tile grids, 98-workgroup 7x7 levels).
         nsub = int(getattr(self.cfg.model, "engine_streams", 2))
         if nsub > 1 and B % nsub == 0 and B // nsub >= 32 and getattr(self.cfg.model, "engine_graph", True):
-            key = (B, x.dtype, nsub)
+            key = (B, x.dtype, nsub, lb)
             grp = self._plans.get(key)
             Bs = B // nsub
             xs = x.reshape(B, -1)
             if grp is None:
                 C_, H_, W_ = self.cfg.data.shape
-                logits = torch.empty((B, C_ * H_ * W_, self.net.S), dtype=torch.float32, device=self.dev)
-                subs = [self._prepare(Bs, x.dtype, xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs], logits[i * Bs:(i + 1) * Bs])
-                        for i in range(nsub)]
+                logits = torch.empty((B, C_ * H_ * W_, self.net.S), dtype=torch.bfloat16 if lb else torch.float32, device=self.dev)
+                subs = [self._prepare(Bs, x.dtype, xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs], logits[i * Bs:(i + 1) * Bs],
+                                      logits_bf16=lb) for i in range(nsub)]
                 grp = self._plans[key] = (logits, subs, [torch.cuda.Stream(device=self.dev) for _ in range(nsub - 1)])
             logits, subs, streams = grp
             if all(s.graph is not None for s in subs):
@@ -602,10 +609,10 @@ class UNetEngine:
                 for ev in done:
                     main.wait_event(ev)
                 return logits
-        key = (B, x.dtype)
+        key = (B, x.dtype, lb)
         st = self._plans.get(key)
         if st is None:
-            st = self._plans[key] = self._prepare(B, x.dtype, x, times)
+            st = self._plans[key] = self._prepare(B, x.dtype, x, times, logits_bf16=lb)
         st.x_in.copy_(x.reshape(st.x_in.shape))
         st.t_in.copy_(times.float())
         if st.graph is not None:

@@ -34,16 +34,20 @@ class borrow_engine_output:
     """`with borrow_engine_output(model):` -- inside, model(x, t) returns the engine plan's own logits buffer
     (no copy); the next forward overwrites it.  The sampler loops consume logits within a step and use this."""
 
-    def __init__(self, model):
+    def __init__(self, model, bf16_logits=False):
+        """bf16_logits: the U-Net engine's output convolution writes (B, D, S) logits in bf16 (bf16 engine, `logits` head only;
+        any other model ignores the request and returns fp32) -- what the S = 256 bf16 step kernel reads."""
         self.model = model
+        self.bf16_logits = bool(bf16_logits)
 
     def __enter__(self):
-        self.prev = getattr(self.model, "_borrow_engine_output", False)
+        self.prev = (getattr(self.model, "_borrow_engine_output", False), getattr(self.model, "_engine_logits_bf16", False))
         self.model._borrow_engine_output = True
+        self.model._engine_logits_bf16 = self.bf16_logits
         return self.model
 
     def __exit__(self, *exc):
-        self.model._borrow_engine_output = self.prev
+        self.model._borrow_engine_output, self.model._engine_logits_bf16 = self.prev
         return False
 
 
@@ -154,7 +158,7 @@ class ImageX0PredBasePaul(nn.Module):
                 finally:
                     inner._engine_hook = None
             return self._engine.train_forward(x, times)
-        out = self._engine(x, times)
+        out = self._engine(x, times, logits_bf16=bool(getattr(self, "_engine_logits_bf16", False)))
         # the plan owns its output buffer: hand out a copy unless the caller (a sampler loop that consumes the
         # logits before the next forward) asked to borrow it -- two live results must not alias
         return out if getattr(self, "_borrow_engine_output", False) else out.clone()

@@ -109,6 +109,24 @@ class _GridSampler:
             return native.S256Tables(qt0, model.process.base_rate, 0.0, crm=True, bf16=bf16)
         return None
 
+    def _borrow(self, model):
+        """Context for the sampler loops: the engine's own logits buffer is borrowed (no copy per step), and when the S = 256
+        step runs its single-product bf16 mode the U-Net engine's output convolution writes the logits in bf16
+        (cfg.sampler.logits_bf16, default True: half the bytes of the step's one large write and read; the rounding, 2^-8 of a
+        logit, is below the bf16 network's own error)."""
+        bf = (self.S == 256 and self._needs_qt0() and getattr(self.cfg.sampler, "fast_s256", True)
+              and (self.branch == native.BRANCH_CTELBO or self.logit_type == "reverse_prob")
+              and self._step_bf16(model) and bool(getattr(self.cfg.sampler, "logits_bf16", True)))
+        return borrow_engine_output(model, bf16_logits=bf)
+
+    @staticmethod
+    def _net_logits(model, x, t, fast=None):
+        """model(x, t) as the step kernels take it: bf16 straight through to the bf16 step (fast.bf16), fp32 otherwise."""
+        out = model(x.long(), t)
+        if out.dtype == torch.bfloat16 and fast is not None and fast.bf16:
+            return out.contiguous()
+        return out.float().contiguous()
+
     def _step_bf16(self, model):
         """cfg.sampler.step_precision: "bf16" = one bf16 product for the S x S ratio contraction (relative rate error <= 3 * 2^-8),
         "fp32" = three split-bf16 products (<= 3e-5, the parity mode), "auto" (default) = bf16 exactly when the score network
@@ -174,7 +192,7 @@ class TauL(_GridSampler):
 
     def advance(self, st, i):
         """Step i of the grid: network forward, fused reverse-rate/jump/update launch, correctors."""
-        with borrow_engine_output(st.model):
+        with self._borrow(st.model):
             self._advance(st, i)
 
     def _advance(self, st, i):
@@ -183,12 +201,12 @@ class TauL(_GridSampler):
         h = float(np.float32(st.ts[i] - st.ts[i + 1]))
         t_ones = self._t_ones(st.t32, i, N, st.dev)
         q_i = st.qt0[i] if st.qt0 is not None else None
-        logits = model(st.x.long(), t_ones).float().contiguous()
+        logits = self._net_logits(model, st.x, t_ones, st.fast)
         st.x = self._leap(model, logits, st.x, q_i, st.fast, i, st.betas[i], h, st.flags, st.key, i * st.sub,
                           changed=st.changed[i:i + 1])
         if t <= self.corrector_entry_time:
             for c in range(self.num_corrector_steps):
-                logits = model(st.x.long(), t_ones).float().contiguous()
+                logits = self._net_logits(model, st.x, t_ones, st.fast)
                 st.x = self._leap(model, logits, st.x, q_i, st.fast, i, st.betas[i], h,
                                   st.flags | native.STEP_CORRECTOR, st.key, i * st.sub + 1 + c)
 
@@ -199,7 +217,7 @@ class TauL(_GridSampler):
         return x.cpu().numpy().astype(int), (st.changed.cpu().numpy() / st.N).tolist()
 
     def sample(self, model, N):
-        with torch.no_grad(), borrow_engine_output(model):
+        with torch.no_grad(), self._borrow(model):
             st = self.begin(model, N)
             for i in range(self.num_steps):
                 self.advance(st, i)
@@ -220,7 +238,7 @@ class LBJF(_GridSampler):
     def sample(self, model, N):
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad(), borrow_engine_output(model):
+        with torch.no_grad(), self._borrow(model):
             x = self._initial(model, N, key, self.cfg.model.Q_sigma)
             ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
             t32, qt0, betas = self._tables(model, ts[:-1])
@@ -231,11 +249,11 @@ class LBJF(_GridSampler):
                 h = float(np.float32(ts[i] - ts[i + 1]))
                 t_ones = self._t_ones(t32, i, N, dev)
                 q_i = qt0[i] if qt0 is not None else None
-                logits = model(x.long(), t_ones).float().contiguous()
+                logits = self._net_logits(model, x, t_ones, fast)
                 x = self._lbjf(model, logits, x, q_i, fast, i, betas[i], h, 0, key, i * sub, changed=changed[i:i + 1])
                 if t <= self.corrector_entry_time:
                     for c in range(self.num_corrector_steps):
-                        logits = model(x.long(), t_ones).float().contiguous()
+                        logits = self._net_logits(model, x, t_ones, fast)
                         x = self._lbjf(model, logits, x, q_i, fast, i, betas[i], h, native.STEP_CORRECTOR, key, i * sub + 1 + c)
             if self.loss_name == "CTElbo":
                 x = self._final_argmax(model, x, N)
@@ -258,7 +276,7 @@ class MidPointTauL(_GridSampler):
     def sample(self, model, N):
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad(), borrow_engine_output(model):
+        with torch.no_grad(), self._borrow(model):
             x = self._initial(model, N, key, self.cfg.model.Q_sigma)
             h = (self.max_t - self.min_t) / self.num_steps
             full, half, t = [], [], self.max_t
@@ -283,7 +301,7 @@ class MidPointTauL(_GridSampler):
             for i in range(nst):
                 t_ones = torch.full((N,), float(t32[i]), device=dev)
                 t_05 = torch.full((N,), float(t32_half[i]), device=dev)
-                logits = model(x.long(), t_ones).float().contiguous()
+                logits = self._net_logits(model, x, t_ones, fast_full)
                 if fast_full is not None:           # S = 256: rates from the matrix-core kernel, drift on them
                     _, rates = native.tauleap_step_s256(logits, x, fast_full, i, b_full[i], hf, 0, key, 0, want_rates=True,
                                                         want_x=False)
@@ -292,7 +310,7 @@ class MidPointTauL(_GridSampler):
                     x_prime = native.midpoint_predict(self.branch, self.logit_type, logits, x,
                                                       q_full[i] if need_q else None, pr.base_rate, b_full[i],
                                                       self.eps_ratio, h)
-                logits_p = model(x_prime.long(), t_05).float().contiguous()
+                logits_p = self._net_logits(model, x_prime, t_05, fast_half)
                 x_new = self._leap(model, logits_p, x, q_half[i] if need_q else None, fast_half, i, b_half[i], hf,
                                    flags, key, i, x_base=x_prime, changed=cnt[i, 0:3])
                 cnt[i, 3] = (x != x_prime).sum()
@@ -322,7 +340,7 @@ class PCTauL(_GridSampler):
         s = self.cfg.sampler
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad(), borrow_engine_output(model):
+        with torch.no_grad(), self._borrow(model):
             x = self._initial(model, N, key, 200)
             h0 = 1.0 / s.num_steps
             ts = np.linspace(1.0, s.min_t + h0, s.num_steps)
@@ -332,7 +350,7 @@ class PCTauL(_GridSampler):
             sub = 1 + max(int(s.num_corrector_steps), 0)
             for i, t in enumerate(ts[:-1]):
                 h = ts[i] - ts[i + 1]
-                logits = model(x.long(), self._t_ones(t32, i, N, dev)).float().contiguous()
+                logits = self._net_logits(model, x, self._t_ones(t32, i, N, dev), fast)
                 x = self._leap(model, logits, x, qt0[i], fast, i, betas[i], float(np.float32(h)), native.STEP_ORDINAL,
                                key, i * sub)
                 if t <= s.corrector_entry_time:
@@ -342,7 +360,7 @@ class PCTauL(_GridSampler):
                     t_c = torch.full((N,), float(tc[0]), device=dev)
                     fast_c = self._fast_tables(model, qc.unsqueeze(0)) if fast is not None else None
                     for c in range(s.num_corrector_steps):
-                        logits = model(x.long(), t_c).float().contiguous()
+                        logits = self._net_logits(model, x, t_c, fast_c)
                         x = self._leap(model, logits, x, qc, fast_c, 0, bc, float(np.float32(s.corrector_step_size_multiplier * h)),
                                        native.STEP_ORDINAL | native.STEP_CORRECTOR, key, i * sub + 1 + c)
             x = self._final_argmax(model, x, N)

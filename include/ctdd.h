@@ -53,6 +53,8 @@ extern "C" {
 #define CTDD_STEP_BF16 32u       /* ctdd_tauleap_step_s256 only: ONE bf16 product for the S x S contraction (the mode the bf16 score
                                   * network runs with; all terms are >= 0, relative rate error <= 3 * 2^-8) instead of the three
                                   * split-bf16 products of the fp32 parity mode.  Same tables, same draw rule. */
+#define CTDD_STEP_LOGITS_BF16 64u /* with CTDD_STEP_BF16: `logits` points at (N,D,256) bf16 values (what the bf16 U-Net engine's
+                                  * output convolution writes on request) instead of f32 */
 
 int ctdd_abi_version(void);
 const char* ctdd_last_error(void);
@@ -183,7 +185,7 @@ int ctdd_s256_prepare_crm(const float* qt0, const float* base_rate, int nT, void
 /* Same semantics as ctdd_tauleap_step(branch = CTELBO) for S = 256 (lib/sampling/sampling.py:
  * 119-160, 165-221, 459-508).  step_tables points at THIS step's block.  out_rates (N,D,256),
  * optional, receives the masked reverse rates (validation / unfused use); out_x may then be NULL. */
-int ctdd_tauleap_step_s256(const float* logits, const int32_t* x, const int32_t* x_base,
+int ctdd_tauleap_step_s256(const void* logits /* f32; bf16 with CTDD_STEP_LOGITS_BF16 */, const int32_t* x, const int32_t* x_base,
                            const void* step_tables, const float* RT0, const float* R0, float beta,
                            float h, uint32_t flags, uint64_t seed, uint64_t offset, int N, int D,
                            float* out_rates, int32_t* out_x, int32_t* out_changed, void* stream);

@@ -359,3 +359,33 @@ def test_b16_full_size_properties_and_jump_law(env):
     assert abs(zscore) < 5.0, zscore
     ratio = float(((J - mean)[inner] ** 2).sum() / var[inner].sum())
     assert abs(ratio - 1.0) < 0.05, ratio
+
+
+def test_b16_bf16_logits_input(env):
+    """CTDD_STEP_LOGITS_BF16: the bf16 kernel reading bf16 logits (what the bf16 U-Net engine's output convolution writes on
+    request) against the same kernel reading the same values widened to fp32 -- same rates up to the order of the row sums, same
+    draws up to float near-ties; and the ragged tail / x_base / rate output of the general variant."""
+    native, pr, op = env
+    N, D = 3, 211
+    logits, x = _case(N, D, 41, 3.0)
+    lb = logits.to(torch.bfloat16)
+    tt = torch.tensor([0.45])
+    qt0 = pr.tables(tt, want_qt0=True)[0]
+    beta = float(pr.beta(tt)[0])
+    tabs = native.S256Tables(qt0, pr.base_rate, 1e-9, bf16=True)
+    dx = x.to(torch.int32).cuda()
+    d16, d32 = lb.cuda().contiguous(), lb.float().cuda().contiguous()
+    _, r16 = native.tauleap_step_s256(d16, dx, tabs, 0, beta, 1e-3, 1, 3, 0, want_rates=True, want_x=False)
+    _, r32 = native.tauleap_step_s256(d32, dx, tabs, 0, beta, 1e-3, 1, 3, 0, want_rates=True, want_x=False)
+    np.testing.assert_allclose(r16.cpu().numpy(), r32.cpu().numpy(), rtol=1e-5, atol=1e-30)
+    q, r = op.transition(tt).repeat(N, 1, 1), op.rate(tt).repeat(N, 1, 1)
+    ref = ops.zero_own_state(ops.reverse_rates_ctelbo(lb.float(), x, q, r, 1e-9)[0], x)
+    np.testing.assert_allclose(r16.cpu().numpy(), ref.numpy(), rtol=B16_RTOL, atol=1e-25)
+    h = float(1.0 / ref.sum(-1).median())
+    for flags in (1, 0, 3):
+        a16 = native.tauleap_step_s256(d16, dx, tabs, 0, beta, h, flags, 7, 2).cpu()
+        a32 = native.tauleap_step_s256(d32, dx, tabs, 0, beta, h, flags, 7, 2).cpu()
+        assert (a16 != a32).float().mean().item() < 3e-3
+        assert (a16 != x).float().mean() > 0.05
+    with pytest.raises(native.CtddError):                  # bf16 logits are for the bf16 step only
+        native.tauleap_step_s256(d16, dx, native.S256Tables(qt0, pr.base_rate, 1e-9), 0, beta, h, 1, 7, 2)

@@ -148,23 +148,33 @@ def test_eval_forwards_do_not_alias():
 def test_engine_sub_batch_streams_match_single_plan():
     """The headline path: a batch replayed as two HIP-graph sub-batches on parallel streams into slices of one logits
     buffer (engine_streams = 2) against one full-batch plan (engine_streams = 1), over consecutive calls with new inputs."""
-    from ctdd.unet_engine import UNetEngine
     cfg, model = _mnist_model(seed=3)
     model.eval()
-    B = 64
+    _sub_batch_streams_case(cfg, model, 64)
+
+
+def test_engine_sub_batch_streams_at_bench_size():
+    """The same at the size bench.py runs: 256 samples = two 128-sample plans (the kernel selection of the headline)."""
+    cfg, model = _mnist_model(seed=4)
+    model.eval()
+    _sub_batch_streams_case(cfg, model, 256, iters=3)
+
+
+def _sub_batch_streams_case(cfg, model, B, iters=4):
+    from ctdd.unet_engine import UNetEngine
     with torch.no_grad():
         cfg.model.engine_streams = 2
         e2 = UNetEngine(model, precision="bf16")
         cfg.model.engine_streams = 1
         e1 = UNetEngine(model, precision="bf16")
-        for it in range(4):
+        for it in range(iters):
             x = torch.randint(0, 256, (B, 1, 28, 28), device="cuda")
             t = torch.rand(B, device="cuda") * 0.98 + 0.01
             cfg.model.engine_streams = 2
             o2 = e2(x, t).clone()
             cfg.model.engine_streams = 1
             o1 = e1(x, t).clone()
-            assert any(len(k) == 3 for k in e2._plans) and all(len(k) == 2 for k in e1._plans)
+            assert any(len(k) == 4 for k in e2._plans) and all(len(k) == 3 for k in e1._plans)    # (B, dtype, streams, bf16 logits) / (B, dtype, bf16 logits)
             cfg.model.engine = "torch"
             ref = model(x.view(B, -1), t)
             cfg.model.engine = "hip"
@@ -276,3 +286,34 @@ def test_slab_conv_kernels(kernel, B, H, W, segs, N, ksplit, bnt):
     want = torch.stack([out.double().view(B, H * W, N).sum(1), (out.double() ** 2).view(B, H * W, N).sum(1)], -1)
     # fp32 sums over blocks of eight rows, fp64 above that: ~1e-7 of sqrt(n * sum of squares)
     torch.testing.assert_close(stats, want, rtol=1e-5, atol=1e-3)
+
+
+def test_engine_bf16_logits_on_request():
+    """borrow_engine_output(model, bf16_logits=True): the output convolution writes the (B, D, S) logits in bf16 -- the same
+    values as the fp32 logits rounded once (the two plans share every kernel; GroupNorm statistics meet in atomics, so the fp32
+    values themselves may differ in their last bits)."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from lib.models.models import borrow_engine_output
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.device = "cuda"
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for B in (3, 64):                                      # one plan / two sub-batch plans on parallel streams
+        x = torch.randint(0, 256, (B, 784), device="cuda", generator=g)
+        t = torch.rand(B, device="cuda", generator=g) * 0.9 + 0.05
+        with torch.no_grad():
+            f32 = model(x, t)
+            with borrow_engine_output(model, bf16_logits=True):
+                b16 = model(x, t)
+                assert b16.dtype == torch.bfloat16 and b16.shape == f32.shape
+                b16 = b16.float().clone()
+            with borrow_engine_output(model):
+                again = model(x, t)
+                assert again.dtype == torch.float32
+        assert f32.dtype == torch.float32
+        err = (b16 - f32).abs()
+        assert (err <= f32.abs() * 2.0 ** -8 + 1e-6).all(), float((err / f32.abs().clamp_min(1e-3)).max())
