@@ -698,7 +698,10 @@ class HollowTrainer:
         p_drop = float(m.dropout_rate) if training else 0.0
         p_att = float(m.attention_dropout_rate) if training else 0.0
         self._pack_weights(bump=training)                     # (+ one dropout stream per training forward)
-        rng, pk = self.rng, self.pk
+        # every forward keeps its OWN {seed, step}: the Functions save this tensor and their backward kernels read the step
+        # from it, so a second training forward before the first one's backward (two-forward-pass CT-ELBO, gradient
+        # accumulation over micro-batches) must not move the first one's masks
+        rng, pk = (self.rng.clone() if training else self.rng), self.pk
         layer = [0]
 
         def nxt():

@@ -140,7 +140,17 @@ class ImageX0PredBasePaul(nn.Module):
             _warn_once(self, "unet-dtype", f"HIP engine takes integer states, got {x.dtype}; running torch device ops")
             return False
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            return unet_engine.training_supported(self)
+            ok = unet_engine.training_supported(self)
+            if not ok:
+                _warn_once(self, "unet-train", "U-Net outside the HIP training plan's coverage (channel counts must be multiples of 16); "
+                                               "training runs on torch device ops")
+            return ok
+        if self.training and float(getattr(self.cfg.model, "dropout", 0.0)) > 0.0:
+            # train mode without gradients (torch.no_grad() around a train-mode forward): the reference applies dropout whenever
+            # the module is in train mode (unet.py:100-140); the inference plan has none, so this case runs the module itself
+            _warn_once(self, "unet-train-nograd", "train-mode forward without gradients: dropout is active, running torch device ops "
+                                                  "(call model.eval() for the HIP inference plan)")
+            return False
         return True
 
     def _engine_forward(self, x, times):

@@ -412,9 +412,12 @@ def lbjf_corrector_step(cfg, model, xt, t, h, N, device, xt_target=None, seed=No
     takes the rate row of the DIMENSION index, and it passes log-probabilities to Categorical as `probs`); nothing calls
     it.  This is the formula its docstring and the LBJF corrector (sampling.py:296-341) state: rate row of the STATE
     x_t, Categorical(logits=log posterior).  Parity: oracle restatement `oracle.samplers.lbjf_corrector_posterior`
-    (reference fixture impossible: parity unpinned)."""
+    (reference fixture impossible: parity unpinned).  `t` may be a tensor only if all its entries are equal."""
     if torch.is_tensor(t):
-        t = float(t.reshape(-1)[0])
+        tv = t.reshape(-1)
+        if tv.numel() > 1 and not bool((tv == tv[0]).all()):
+            raise ValueError("lbjf_corrector_step: every sample shares one time (the reference multiplies a scalar t by ones((N,)))")
+        t = float(tv[0])
     t32 = torch.tensor([t], dtype=torch.float64).to(torch.float32)
     t_ones = torch.full((N,), float(t32[0]), device=device, dtype=torch.float32)
     with torch.no_grad():
@@ -423,12 +426,25 @@ def lbjf_corrector_step(cfg, model, xt, t, h, N, device, xt_target=None, seed=No
     pr = model.process
     q = pr.tables(t32, want_qt0=True)[0][0] if lt != "direct" else None
     beta = float(pr.beta(t32)[0])
-    if xt_target is not None and xt_target is not xt and not torch.equal(xt_target, xt):
-        raise NotImplementedError("lbjf_corrector_step: xt_target != xt (own-state mask of another state) is not built; "
-                                  "no reference caller uses it")
-    out = native.lbjf_step(native.BRANCH_CRM, lt, logits, xt.to(torch.int32).contiguous(), q, pr.base_rate, beta,
-                           cfg.sampler.eps_ratio, float(h), native.STEP_CORRECTOR, E, seed if seed is not None else _fresh_seed(), 0,
-                           want_probs=want_probs)
+    key = seed if seed is not None else _fresh_seed()
+    xi = xt.to(torch.int32).contiguous()
+    if xt_target is None or xt_target is xt or torch.equal(xt_target, xt):
+        out = native.lbjf_step(native.BRANCH_CRM, lt, logits, xi, q, pr.base_rate, beta, cfg.sampler.eps_ratio, float(h),
+                               native.STEP_CORRECTOR, E, key, 0, want_probs=want_probs)
+    else:
+        # xt_target != xt (sampling.py:1064-1067, 1076-1080): ratios and forward-rate row of x_t, the own-state mask and the
+        # diagonal at x_target.  K5 gives R^ = ratio * R_t[x_t, :]; add the corrector's forward row, zero the target's entry,
+        # and the Euler posterior + categorical draw of K7 run on those rates with x_target as the state.  The rate row's own
+        # entry R_t[x_t, x_t] = -sum of the row is not a jump rate: it is zeroed too (as written, the reference leaves that
+        # negative number in the "posterior" whenever x_target != x_t and its log is NaN).
+        rate_t = pr.rate(t32)                                               # (1, S, S) = beta(t) R
+        rr, _ = native.reverse_rates(native.BRANCH_CRM, lt, logits, xi, q.unsqueeze(0) if q is not None else None, rate_t,
+                                     cfg.sampler.eps_ratio, want_ratio=False)
+        rr = rr + rate_t[0][xt.long()]
+        tgt = xt_target.to(torch.int32).contiguous()
+        rr.scatter_(-1, xt.long().unsqueeze(-1), 0.0)
+        rr.scatter_(-1, tgt.long().unsqueeze(-1), 0.0)
+        out = native.lbjf_from_rates(rr.contiguous(), tgt, float(h), E, key, 0, want_probs=want_probs)
     return (out[0].long(), out[1]) if want_probs else out.long()
 
 

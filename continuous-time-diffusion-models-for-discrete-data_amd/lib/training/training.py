@@ -40,7 +40,9 @@ class Standard:
         opt, model = state["optimizer"], state["model"]
         if self.warmup > 0:                                   # (the reference sets the LR after clipping; the two commute)
             for g in opt.param_groups:
-                g["lr"] = self.lr * np.minimum(state["n_iter"] / self.warmup, 1.0)
+                # (a python float: the reference stores numpy's float64 here, which ends up in the optimizer's state_dict
+                #  and makes its checkpoints need an allow-listed numpy global to load safely -- bookkeeping.load_state)
+                g["lr"] = float(self.lr * np.minimum(state["n_iter"] / self.warmup, 1.0))
         owner = model.module if hasattr(model, "module") else model      # DDP wrapper
         first = next(model.parameters())
         if first.is_cuda and hasattr(opt, "fused_step"):

@@ -29,10 +29,29 @@ def save_state(state: dict, save_dir) -> None:
     torch.save(ckpt, os.path.join(path, f"model_{state['n_iter']}.pt"))
 
 
+def _numpy_scalar_globals():
+    """The reference's warm-up writes a numpy float64 learning rate into the optimizer's param_groups
+    (training.py:31-33), so its checkpoints pickle a numpy scalar.  Reconstructing a numpy scalar executes nothing from the
+    file: allow-list exactly those constructors (numpy 1.x and 2.x module paths) for the weights-only loader."""
+    import numpy as np
+    out = [np.dtype]
+    for modname in ("numpy._core.multiarray", "numpy.core.multiarray"):
+        try:
+            mod = __import__(modname, fromlist=["scalar"])
+            out.append(mod.scalar)
+        except (ImportError, AttributeError):
+            pass
+    for name in ("Float64DType", "Float32DType", "Int64DType", "Int32DType", "BoolDType"):
+        if hasattr(np, "dtypes") and hasattr(np.dtypes, name):
+            out.append(getattr(np.dtypes, name))
+    return out
+
+
 def load_state(state: dict, checkpoint_path: str, mapping=torch.device("cuda")) -> dict:
-    # our own / the reference's checkpoints hold tensors, python scalars and a list of tensors
-    # (ema_shadow_params): loadable with weights_only=True
-    ckpt = torch.load(checkpoint_path, map_location=mapping, weights_only=True)
+    # our own / the reference's checkpoints hold tensors, python and numpy scalars and a list of tensors
+    # (ema_shadow_params): loadable with weights_only=True (nothing from the file is executed)
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        ckpt = torch.load(checkpoint_path, map_location=mapping, weights_only=True)
     state["model"].load_state_dict(ckpt["model"])
     state["optimizer"].load_state_dict(ckpt["optimizer"])
     state["n_iter"] = ckpt["n_iter"]

@@ -195,15 +195,21 @@ def exact_sample(model, N, D, S, *, max_t, min_t, num_steps, initial_dist, init_
     return x.numpy().astype(int), change
 
 
-def lbjf_corrector_posterior(model, logits, xt, t_ones, h, logit_type):
+def lbjf_corrector_posterior(model, logits, xt, t_ones, h, logit_type, xt_target=None):
     """lbjf_corrector_step (sampling.py:1064-1085) as its docstring and the LBJF corrector (296-341) state it:
     posterior = h * (exp(ll_all - ll_xt) + 1) * R_t[x_t, :] off the own state, clip(1 - sum, 0) on it, normalised.
     (The reference body multiplies the (N,D,S) ratio by the (N,S,S) `model.rate(t)`: it only runs for D == S and then
-    takes the rate row of the dimension index; nothing in the reference calls it.)  Returns (N, D, S) probabilities."""
+    takes the rate row of the dimension index; nothing in the reference calls it.)  Returns (N, D, S) probabilities.
+    PARITY UNPINNED: the reference function cannot run as written, so no fixture of it exists; this is the builder's reading.
+    xt_target (1066-1067, 1076): the state whose entry is masked and receives the diagonal; ratios and rate row stay x_t's.
+    The rate row's own entry R_t[x_t, x_t] (negative: minus the row sum) is zeroed as well -- with x_target != x_t the
+    reference leaves it in and takes the log of a negative number."""
     qt0 = None if logit_type == "direct" else model.transition(t_ones)
     ll_all, ll_xt = ops.logprob_with_logits(logit_type, logits, xt, qt0)
     fwd = model.rate_mat(xt.long(), t_ones)
-    own = F.one_hot(xt.long(), logits.shape[-1]).to(fwd.dtype)
+    own = F.one_hot((xt if xt_target is None else xt_target).long(), logits.shape[-1]).to(fwd.dtype)
+    if xt_target is not None:
+        fwd = fwd * (1 - F.one_hot(xt.long(), logits.shape[-1]).to(fwd.dtype))
     post = h * (torch.exp(ll_all - ll_xt.unsqueeze(-1)) * fwd + fwd) * (1 - own)
     post = post + torch.clip(1.0 - post.sum(-1, keepdim=True), min=0) * own
     return post / post.sum(-1, keepdim=True)

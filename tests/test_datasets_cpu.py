@@ -1,7 +1,7 @@
-"""CPU: dataset adapters and the MMD metric.  The reference needs torchvision / absl /
-downloads for these modules and was not imported for them: parity unpinned -- format readers are checked
-on files written here, the codec by round trips and Gray-code properties, the MMD against the reference's
-formula written out with dense (N, M, D) differences."""
+"""CPU: dataset adapters and the MMD metric.  The maze solver / `maze_acc`, the Gray codec and the MMD
+are pinned by outputs of the reference itself (tests/golden/aux_*.npz, written by oracle/gen_golden_aux.py; tests at the
+end of this file).  The image loaders (`DiscreteMNIST` / `DiscreteCIFAR10`) stay parity unpinned: the reference's versions
+subclass torchvision and download; here the format readers are checked on files written by the test."""
 import gzip
 import struct
 
@@ -175,3 +175,72 @@ def test_frechet_distance_plumbing():
     assert abs(fid.evaluate_fid_score(x1, x1, model=Feat(), dims=4, device="cpu")) < 1e-5
     with pytest.raises(RuntimeError):
         fid.evaluate_fid_score(x1, x2)
+
+
+# ---------------------------------------------------------------- pinned by outputs of the reference itself
+# tests/golden/aux_*.npz are written by oracle/gen_golden_aux.py from the imported reference (lib/datasets/maze.py,
+# synthetic.py, metrics.py); see that file's header for what was stubbed (command-line / logging imports only).
+def test_maze_solver_and_accuracy_match_the_reference(golden):
+    """`find_path` (maze.py:780-818: entry search, BFS tie-break order) and `maze_acc` (866-898) on mazes the reference's
+    own `maze_gen` drew: the mirror re-solves their bare walls to exactly the reference's solved grids, and keeps exactly the
+    samples the reference's `maze_acc` keeps (clean, corrupted and unsolvable ones)."""
+    import lib.datasets.maze as mz
+    g = golden("aux_maze")
+    for tag, rt in (("fixed", False), ("random", True)):
+        walls, want = g[f"{tag}__walls"], g[f"{tag}__resolved"]
+        for i in range(walls.shape[0]):
+            got = mz.find_path(walls[i].copy(), rt)
+            assert got is not None
+            np.testing.assert_array_equal(got, want[i])
+        np.testing.assert_array_equal(want, g[f"{tag}__solved"])            # (the reference's mazes are their own solved form)
+    kept = mz.maze_acc(g["acc__samples"].copy(), verbose=False)
+    np.testing.assert_array_equal(kept, g["acc__kept"])
+    assert abs(mz.maze_acc.last["accuracy"] - g["acc__kept"].shape[0] / g["acc__samples"].shape[0]) < 1e-12
+
+
+def test_maze_generator_matches_the_reference_in_distribution(golden):
+    """The mirror draws from its own `random.Random` stream, so single mazes differ from the reference's; the LAW is pinned:
+    every maze has the same 126 wall cells (a perfect maze on 7x7 cells + two openings), and the mean solution length, its
+    spread and the share of rotated mazes agree with 400 reference mazes within sampling error."""
+    import lib.datasets.maze as mz
+    g = golden("aux_maze")
+    ref = g["stats__counts"].astype(np.float64)                             # (400, 3): wall / path / floor counts
+    mine = mz.maze_gen(400, random_transform=True, device="cpu", seed=99).numpy().reshape(-1, 15, 15)
+    cnt = np.stack([(mine == s).sum(axis=(1, 2)) for s in (0, 1, 2)], 1).astype(np.float64)
+    assert (cnt[:, 0] == 126).all() and (ref[:, 0] == 126).all()
+    se = np.sqrt(ref[:, 1].var() / 400 + cnt[:, 1].var() / 400)
+    assert abs(cnt[:, 1].mean() - ref[:, 1].mean()) < 4 * se, (cnt[:, 1].mean(), ref[:, 1].mean())
+    assert 0.7 < cnt[:, 1].std() / ref[:, 1].std() < 1.4
+    rot = float((mine[:, 0, :] == 0).all(axis=1).mean())
+    assert abs(rot - float(g["stats__rot_share"][0])) < 4 * np.sqrt(0.25 / 400 * 2)
+    kept = mz.maze_acc(mine, verbose=False)                                 # every generated maze is its own solved form
+    assert kept.shape[0] == 400
+
+
+def test_gray_codec_matches_the_reference(golden):
+    """`float2bin` / `bin2float` (synthetic.py:164-224) in both bin maps: same bits for the same points, same points back."""
+    import lib.datasets.synthetic as sy
+    g = golden("aux_synthetic")
+    for D in (32, 16):
+        for mode in ("gray", "normal"):
+            pts, bits, back = g[f"D{D}__{mode}__points"], g[f"D{D}__{mode}__bits"], g[f"D{D}__{mode}__back"]
+            scale = float(g[f"D{D}__{mode}__scale"][0])
+            got = sy.float2bin(pts, D, scale, binmode=mode)
+            np.testing.assert_array_equal(np.asarray(got), bits)
+            np.testing.assert_allclose(np.asarray(sy.bin2float(bits, D, scale, binmode=mode)), back, rtol=0, atol=1e-12)
+
+
+def test_mmd_matches_the_reference(golden):
+    """`binary_exp_hamming_mmd` (metrics.py:24-56) on seeded bit arrays: the blocked on-device evaluation against the
+    reference's dense (N, M, D) one, two bandwidths, square and ragged shapes."""
+    import lib.datasets.metrics as mt
+    g = golden("aux_metrics")
+    for tag in ("a", "b", "c"):
+        x, y = torch.from_numpy(g[f"{tag}__x"]), torch.from_numpy(g[f"{tag}__y"])
+        for bw in (0.1, 0.5):
+            want = float(g[f"{tag}__mmd_bw{bw}"][0])
+            got = float(mt.binary_exp_hamming_mmd(x, y, None, bandwidth=bw))
+            assert abs(got - want) < 1e-6 + 1e-5 * abs(want), (tag, bw, got, want)
+        sim = g[f"{tag}__sim_bw0.1"]
+        tot = float(mt.exp_hamming_gram_sum(x.float(), y.float(), 0.1))
+        assert abs(tot - float(sim.astype(np.float64).sum())) < 1e-4 * float(sim.sum())

@@ -159,6 +159,44 @@ def test_hollow_train_dropout_masks_are_consistent(golden):
     model.train()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_hollow_train_two_forwards_before_backward_keep_their_masks(golden, precision):
+    """A second training forward before the first one's backward (the two-forward-pass CT-ELBO, `model(x_t)` then
+    `model(x_tilde)`; gradient accumulation) must not move the first forward's dropout masks: every forward carries its
+    own {seed, step} snapshot.  Gradients of the interleaved run equal those of each forward run and backpropagated alone."""
+    from ctdd.hollow_train import HollowTrainer
+    cfg, model, x, t, ref = _tiny(golden, "s3", p_drop=0.2, p_att=0.2)
+    tr = HollowTrainer(model, precision=precision)
+    torch.manual_seed(7)
+    w1 = torch.randn(ref.shape, device="cuda")
+    w2 = torch.randn(ref.shape, device="cuda")
+    x2 = (x + 1) % cfg.data.S
+
+    def alone(step, xx, ww):
+        tr.rng[1] = step
+        return _grads(model, lambda: (tr(xx, t) * ww).sum().backward())[1]
+
+    g1 = alone(20, x, w1)                                  # masks of step 21
+    g2 = alone(21, x2, w2)                                 # masks of step 22
+
+    def both():
+        tr.rng[1] = 20
+        o1 = tr(x, t)                                      # step 21
+        o2 = tr(x2, t)                                     # step 22, before the first backward
+        ((o1 * w1).sum() + (o2 * w2).sum()).backward()
+
+    gb = _grads(model, both)[1]
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    for n, a in g1.items():
+        if a is None:
+            continue
+        want = a + g2[n]
+        scale = max(float(want.abs().max()), 1e-6)
+        err = float((gb[n] - want).abs().max()) / scale
+        # (bf16: the sum of two backward passes accumulates in another order; fp32 atomics of the weight-gradient kernel likewise)
+        assert err < tol, f"{n}: interleaved forwards changed the gradient by {err:.3e} of its range"
+
+
 def test_hollow_train_dropout_rate():
     """The attention-probability dropout keeps 1 - p of the entries and rescales by 1 / (1 - p)."""
     from ctdd.hollow_train import AttentionFn, DropoutFn, ActFn

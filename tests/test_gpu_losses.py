@@ -177,9 +177,12 @@ def test_crm_reverse_logit_types_match_oracle_formulas(S, D, logit_type, loss_ty
 
 @pytest.mark.parametrize("S,D,B", [(256, 50, 3), (32, 37, 4), (96, 130, 2)])
 def test_logprob_reverse_prob_matrix_core_path_matches_generic(S, D, B):
-    """ctdd_logprob_rp_mfma / ctdd_logprob_rp_bwd_mfma (S x S contractions on v_mfma_f32_32x32x2_f32) against the generic row
-    kernels (fp32 FMA chains) on the same inputs: forward log-probabilities, backward d/dlogits with the cross-entropy term."""
+    """ctdd_logprob_rp_mfma / ctdd_logprob_rp_bwd_mfma (S x S contractions on v_mfma_f32_32x32x2_f32) against the ORACLE
+    (oracle.ctmc_ops.logprob_with_logits, model_utils.py:30-60; d/dlogits by autograd through it in float64) and against the
+    generic row kernels (fp32 FMA chains) on the same inputs: forward log-probabilities, backward d/dlogits with the
+    cross-entropy term."""
     from ctdd import native
+    from oracle import ctmc_ops as ops
     g = torch.Generator().manual_seed(S + D)
     logits = (torch.randn(B, D, S, generator=g) * 2).cuda()
     x = torch.randint(0, S, (B, D), generator=g).to(torch.int32).cuda()
@@ -191,6 +194,10 @@ def test_logprob_reverse_prob_matrix_core_path_matches_generic(S, D, B):
     ll, llx = native.logprob(logits, x, q, "reverse_prob", tidx, qt0T=qT)
     np.testing.assert_allclose(ll.cpu().numpy(), ll_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(llx.cpu().numpy(), llx_ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # the independent reference: the oracle's restatement on the CPU (fp32 for the values, float64 autograd for the gradient)
+    ll_o, llx_o = ops.logprob_with_logits("reverse_prob", logits.cpu(), x.cpu(), q.cpu())
+    np.testing.assert_allclose(ll.cpu().numpy(), ll_o.numpy(), rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(llx.cpu().numpy(), llx_o.numpy(), rtol=2e-5, atol=5e-6)
     dll = torch.randn(B, D, S, generator=g).cuda()
     for x0_, w in ((None, 0.0), (x0, 0.37)):
         g_ref, ce_ref = native.logprob_bwd("reverse_prob", logits, q, qT, dll, x0_, w)
@@ -198,3 +205,14 @@ def test_logprob_reverse_prob_matrix_core_path_matches_generic(S, D, B):
         scale = float(g_ref.abs().max())
         assert float((g_new - g_ref).abs().max()) < 2e-5 * scale
         np.testing.assert_allclose(float(ce_new), float(ce_ref), rtol=1e-5, atol=1e-6)
+        l64 = logits.cpu().double().requires_grad_(True)
+        ll64, _ = ops.logprob_with_logits("reverse_prob", l64, x.cpu(), q.cpu().double())
+        obj = (ll64 * dll.cpu().double()).sum()
+        ce64 = torch.zeros((), dtype=torch.float64)
+        if x0_ is not None:                                   # + w * sum_{b,d} -log_softmax(logits)[x0]
+            ce64 = -torch.log_softmax(l64, -1).gather(-1, x0_.cpu().long().unsqueeze(-1)).sum()
+            obj = obj + w * ce64
+        g64, = torch.autograd.grad(obj, l64)
+        assert float((g_new.cpu().double() - g64).abs().max()) < 5e-5 * float(g64.abs().max())
+        if x0_ is not None:
+            np.testing.assert_allclose(float(ce_new), w * float(ce64), rtol=2e-5)     # (the kernels return the weighted term)

@@ -283,6 +283,48 @@ def test_bookkeeping_roundtrip(tmp_path):
     assert torch.equal(model.shadow_params[0], model2.shadow_params[0])
 
 
+def test_reference_checkpoint_loads_into_the_mirror(golden):
+    """tests/golden/aux_checkpoint/model_3.pt was written by the REFERENCE's `save_state` (bookkeeping.py:343-359) after
+    three reference training steps with warm-up (so the optimizer state carries numpy's float64 learning rate, which a plain
+    weights-only load refuses).  The mirror's `load_state` restores it -- model, the three EMA keys, Adam moments, n_iter --
+    and the restored mirror model reproduces the reference model's logits with the live and with the EMA weights
+    (oracle/gen_golden_aux.py froze them).  save_config / load_config stay parity unpinned (ruamel.yaml is absent here)."""
+    import ast
+    mu, _, _, _, ou = _load_lib()
+    import lib.utils.bookkeeping as bk
+    from config.synthetic_config.config_hollow_synthetic import get_config
+    g = golden(os.path.join("aux_checkpoint", "aux_checkpoint"))
+    meta = ast.literal_eval(str(g["cfg"]))
+    cfg = get_config()
+    cfg.device = "cpu"
+    cfg.data.S = meta["S"]
+    cfg.model.name = "UniVarHollowEMA"
+    for k in ("concat_dim", "embed_dim", "num_layers", "num_heads", "mlp_dim", "qkv_dim", "readout_dim", "ema_decay", "rate_const", "t_func"):
+        cfg.model[k] = meta[k]
+    cfg.model.dropout_rate = cfg.model.attention_dropout_rate = 0.0
+    torch.manual_seed(123)                                    # (different initial weights: everything must come from the file)
+    model = mu.create_model(cfg, torch.device("cpu"))
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_checkpoint", "model_3.pt")
+    with pytest.raises(Exception):                             # the numpy scalar: not loadable without the allow-list
+        torch.load(path, map_location="cpu", weights_only=True)
+    state = bk.load_state(state, path, torch.device("cpu"))
+    assert state["n_iter"] == int(g["n_iter"][0]) == 3
+    assert model.num_updates == int(g["ema_num_updates"][0])
+    assert abs(float(state["optimizer"].param_groups[0]["lr"]) - float(g["lr"][0])) < 1e-12
+    assert all(len(v) > 0 for v in state["optimizer"].state_dict()["state"].values())          # Adam moments came along
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
+    with torch.no_grad():
+        live = model(x, t)
+    model.eval()
+    with torch.no_grad():
+        ema = model(x, t)
+    model.train()
+    np.testing.assert_allclose(live.numpy(), g["logits_live"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ema.numpy(), g["logits_ema"], rtol=0, atol=2e-5)
+    assert np.abs(g["logits_live"] - g["logits_ema"]).max() > 1e-4                              # (the two weight sets do differ)
+
+
 # ------------------------------------------------------------------ data-parallel training (gloo, CPU, world size 2)
 class _MbLoss:
     """A loss whose gradient depends on the rank's minibatch."""
