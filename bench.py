@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode timing")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 3-5 block")
     ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
     ap.add_argument("--model-opt", action="append", default=[], help="integer engine option, key=value (tuning sweeps)")
     return ap.parse_args()
@@ -192,7 +193,8 @@ def fp32_parity_mode(cfg, model, sampler, batch, steps=6, warmup=2):
     finally:
         cfg.model.engine_precision, model._engine = prev_prec, prev_eng
     return {"value": round(batch * steps / el, 2), "unit": "sample-steps/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
-            "dtype": "f32", "note": "score network on v_mfma_f32_32x32x2_f32 (logits within 1e-4 of the reference's goldens); same fused tau-leap launch"}
+            "dtype": "f32", "note": "score network on v_mfma_f32_32x32x2_f32 (logits within 1e-4 of the reference's goldens); tau-leap step on the three-product "
+                    "split-bf16 kernel k_tauleap_s256 (rates within 1e-4 of the oracle)"}
 
 
 def train_step_timing(batch=64, steps=10, warmup=4):
@@ -208,9 +210,12 @@ def train_step_timing(batch=64, steps=10, warmup=4):
     import lib.training.training_utils as tu
     from config.mnist_config.config_tauUnet_mnist import get_config
     out = {}
-    for tag, engine in (("hip_plan_bf16", "hip"), ("torch_autograd_fp32", "torch")):
+    for tag, engine, prec in (("hip_plan_bf16", "hip", "bf16"), ("hip_plan_fp32", "hip", "fp32"), ("torch_autograd_fp32", "torch", None)):
         cfg = get_config()
         cfg.model.engine = engine
+        if prec:
+            cfg.model.engine_precision = prec
+        n_steps = 3 if prec == "fp32" else steps
         torch.manual_seed(0)
         model = mu.create_model(cfg, torch.device("cuda"))
         state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
@@ -221,14 +226,17 @@ def train_step_timing(batch=64, steps=10, warmup=4):
             state["n_iter"] += 1
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n_steps):
             step.step(state, loss, mb)
             state["n_iter"] += 1
         torch.cuda.synchronize()
-        out[tag] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        out[tag] = round((time.perf_counter() - t0) / n_steps * 1e3, 3)
         del model, state
     return {"workload": f"MNIST tauLDR CT-ELBO training step, batch {batch} (Standard.step: loss + backward + clip + Adam + EMA)",
-            "ms_per_step": out, "speedup": round(out["torch_autograd_fp32"] / out["hip_plan_bf16"], 2)}
+            "ms_per_step": out, "speedup": round(out["torch_autograd_fp32"] / out["hip_plan_bf16"], 2),
+            "speedup_like_for_like_fp32": round(out["torch_autograd_fp32"] / out["hip_plan_fp32"], 2),
+            "note": "speedup = torch autograd fp32 / HIP plan bf16 (kernels AND precision change); speedup_like_for_like_fp32 = the same torch step / "
+                    "the HIP plan on exact-fp32 matrix instructions (1/16 of the bf16 matrix rate)"}
 
 
 def hollow_train_step_timing(batch=128, steps=10, warmup=4):
@@ -244,9 +252,11 @@ def hollow_train_step_timing(batch=128, steps=10, warmup=4):
     import lib.training.training_utils as tu
     from config.maze_config.config_hollow_maze import get_config
     out = {}
-    for tag, engine in (("hip_bf16", "hip"), ("torch_autograd_fp32", "torch")):
+    for tag, engine, prec in (("hip_bf16", "hip", "bf16"), ("hip_fp32", "hip", "fp32"), ("torch_autograd_fp32", "torch", None)):
         cfg = get_config()
         cfg.device, cfg.model.engine = "cuda", engine
+        if prec:
+            cfg.model.engine_train_precision = prec
         torch.manual_seed(0)
         model = mu.create_model(cfg, torch.device("cuda"))
         state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
@@ -264,7 +274,81 @@ def hollow_train_step_timing(batch=128, steps=10, warmup=4):
         out[tag] = round((time.perf_counter() - t0) / steps * 1e3, 3)
         del model, state
     return {"workload": f"maze hollow-transformer ScoreElbo training step, batch {batch} (Standard.step)", "ms_per_step": out,
-            "speedup": round(out["torch_autograd_fp32"] / out["hip_bf16"], 2)}
+            "speedup": round(out["torch_autograd_fp32"] / out["hip_bf16"], 2),
+            "speedup_like_for_like_fp32": round(out["torch_autograd_fp32"] / out["hip_fp32"], 2)}
+
+
+def baseline_configs():
+    """BASELINE.json configs 3-5 next to the headline (config 2), one MI355X, random-init weights, a few steps each:
+    sampler throughput in sample-steps/s (a whole `sampler.sample(model, N)` call: tables, initial draw, the loop, final
+    arg-max where the sampler has one, device-to-host copy) and training steps in ms (Standard.step on the HIP plans)."""
+    import lib.losses.losses  # noqa: F401
+    import lib.losses.losses_utils as lu
+    import lib.models.model_utils as mu
+    import lib.optimizers.optimizers  # noqa: F401
+    import lib.optimizers.optimizers_utils as ou
+    import lib.sampling.sampling_utils as su
+    import lib.training.training  # noqa: F401
+    import lib.training.training_utils as tu
+    from config.cifar10_config.config_tauUnet_cifar10 import get_config as c10
+    from config.maze_config.config_hollow_maze import get_config as maze
+    from config.mnist_config.config_hollow_mnist import get_config as hmnist
+    dev = torch.device("cuda")
+    out = {}
+
+    def sample_rate(key, what, get_config, N, steps, **over):
+        cfg = get_config()
+        cfg.device = "cuda"
+        cfg.sampler.num_steps = steps
+        for k_, v_ in over.items():
+            setattr(cfg.sampler, k_, v_)
+        torch.manual_seed(0)
+        model = mu.create_model(cfg, dev)
+        model.eval()
+        smp = su.get_sampler(cfg)
+        smp.seed = 1
+        smp.sample(model, N)                       # warm-up: plans, graphs, tables
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        smp.sample(model, N)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        calls = steps * (2 if cfg.sampler.name == "MidPointTauL" else 1)
+        out[key] = {"workload": what, "sampler": cfg.sampler.name, "N": N, "steps": steps, "value": round(N * steps / el, 1),
+                    "unit": "sample-steps/s", "ms_per_step": round(el / steps * 1e3, 3), "network_calls_per_step": calls // steps}
+        del model, smp
+        torch.cuda.empty_cache()
+
+    def train_ms(key, what, get_config, shape, S_, B, loss_name=None, steps=5, warmup=3):
+        cfg = get_config()
+        cfg.device = "cuda"
+        if loss_name:
+            cfg.loss.name = loss_name
+        torch.manual_seed(0)
+        model = mu.create_model(cfg, dev)
+        state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+        step, loss = tu.get_train_step(cfg), lu.get_loss(cfg)
+        mb = torch.randint(0, S_, (B,) + tuple(shape), device="cuda")
+        for _ in range(warmup):
+            step.step(state, loss, mb)
+            state["n_iter"] += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step.step(state, loss, mb)
+            state["n_iter"] += 1
+        torch.cuda.synchronize()
+        out[key] = {"workload": what, "loss": cfg.loss.name, "batch": B, "ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 3)}
+        del model, state
+        torch.cuda.empty_cache()
+
+    sample_rate("cifar10_unet_taul", "config 5 sampler: CIFAR-10 tauLDR U-Net (D=3072, S=256, logistic head), TauL", c10, 64, 20)
+    sample_rate("maze_hollow_midpoint", "config 4: maze hollow transformer (D=225, S=3), MidPointTauL", maze, 128, 50, name="MidPointTauL")
+    sample_rate("mnist_hollow_taul", "config 3 sampler: MNIST hollow transformer (D=784, S=256), TauL", hmnist, 32, 10, name="TauL")
+    train_ms("mnist_hollow_catrmnll_train", "config 3: MNIST hollow transformer training step (CatRMNLL, reverse_prob logits)", hmnist,
+             (1, 28, 28), 256, 32, loss_name="CatRMNLL")
+    train_ms("cifar10_unet_ctelbolambda_train", "config 5: CIFAR-10 tauLDR U-Net training step (CTElboLambda)", c10, (3, 32, 32), 256, 32)
+    return out
 
 
 def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
@@ -383,6 +467,8 @@ def main():
         if world == 1 and not a.no_train_step:
             line["train_step"] = train_step_timing()
             line["train_step_hollow"] = hollow_train_step_timing()
+        if world == 1 and not a.no_configs:
+            line["configs"] = baseline_configs()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, cfg, a.cpu_batch)
         print(json.dumps(line), flush=True)
