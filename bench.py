@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 parity-mode timing")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step timing")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 3-5 block")
+    ap.add_argument("--train", action="store_true",
+                    help="time the data-parallel TRAINING step instead (MNIST tauLDR CT-ELBO, 64 samples per GPU, DDP over RCCL)")
     ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
     ap.add_argument("--model-opt", action="append", default=[], help="integer engine option, key=value (tuning sweeps)")
     return ap.parse_args()
@@ -390,6 +392,63 @@ def cpu_baseline(model_gpu, cfg, batch, budget_s=12.0):
             "sample": f"{done} tau-leaping steps of {batch} samples (oracle U-Net fwd + rates + torch.poisson + update), {el:.1f} s"}
 
 
+def ddp_train_bench(a, world, rank, dev, dist):
+    """`bench.py --gpus N --train`: K data-parallel training steps of the MNIST tauLDR U-Net (CT-ELBO, per-rank batch 64 =
+    config_tauUnet_mnist's batch, global batch 64 N; cfg.distributed wraps the network in DistributedDataParallel: one gradient
+    all-reduce per step over RCCL).  Same timing protocol as the sampling bench: W warm-up steps, barrier + synchronize, K
+    steps, barrier + synchronize, max over ranks."""
+    import lib.losses.losses  # noqa: F401
+    import lib.losses.losses_utils as lu
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.optimizers.optimizers  # noqa: F401
+    import lib.optimizers.optimizers_utils as ou
+    import lib.training.training  # noqa: F401
+    import lib.training.training_utils as tu
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.device = str(dev)
+    cfg.distributed = world > 1
+    B = 64
+    torch.manual_seed(0)                                    # same initial weights on every rank (DDP broadcasts rank 0's anyway)
+    model = mu.create_model(cfg, dev, rank=rank)
+    state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
+    step, loss = tu.get_train_step(cfg), lu.get_loss(cfg)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)  # each rank its own shard of the global minibatch
+    mb = torch.randint(0, S, (B, 1, 28, 28), device=dev, generator=g)
+    K, W = a.steps, max(a.warmup, 3)
+    for _ in range(W):
+        step.step(state, loss, mb)
+        state["n_iter"] += 1
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step.step(state, loss, mb)
+        state["n_iter"] += 1
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    if rank == 0:
+        nparam = sum(p.numel() for p in model.parameters())
+        print(json.dumps({
+            "metric": "data-parallel training samples/s (MNIST tauLDR U-Net, CT-ELBO)", "value": round(B * world * K / el, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, random uint8 images resident in HBM)",
+            "config": {"workload": "MNIST tauLDR CT-ELBO training step (Standard.step: noising, loss, backward, all-reduce, clip, Adam, EMA)",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}: minibatch-sharded, one {nparam * 4 / 2 ** 20:.0f} MB fp32 gradient all-reduce per step (one bucket, after backward)"}}),
+              flush=True)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -412,6 +471,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    if a.train:
+        ddp_train_bench(a, world, rank, dev, dist)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     cfg, model, sampler = build_model(dev)
     if a.engine_streams is not None:
         cfg.model.engine_streams = a.engine_streams

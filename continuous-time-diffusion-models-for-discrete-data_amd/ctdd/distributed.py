@@ -5,8 +5,16 @@ final all_gather of the (n_r, D) integer results.  One process per GPU, torch.di
 RCCL ("nccl" backend) on the GPUs, gloo in the CPU tests.
 
 Training data-parallelism keeps the reference's switch: `cfg.distributed = True` wraps the score
-network in DistributedDataParallel (lib/models/models.py), i.e. one bucketed gradient all-reduce per
-step overlapped with backward; `clip_grad_norm_` then sees identical gradients on every rank.
+network in DistributedDataParallel (lib/models/models.py:_maybe_ddp): the minibatch is sharded over the ranks and the
+gradients are all-reduced once per step; `clip_grad_norm_` then sees identical gradients on every rank.
+  - hollow transformer: one autograd Function per block, 25 MB buckets -> the reduce of the late blocks' gradients overlaps
+    the backward of the early ones;
+  - U-Net: the hand-written backward is one Function whose weight gradients come from one table launch at its end, so the
+    all-reduce is NOT overlapped with backward: it runs as one bucket right after it.  That is deliberate: splitting the
+    weight-gradient table in two stages to expose half of the gradients early costs ~0.4 ms of the 8.6 ms MNIST step
+    (atomic-bound M-split kernels), as much as the whole 56 MB all-reduce is expected to take over xGMI
+    (0.1 ms direct reduce-scatter + all-gather, 0.6 ms on a ring) -- and no multi-GPU node has been available to
+    this build to measure either.  `bench.py --gpus N --train` times the data-parallel step for that day.
 """
 import numpy as np
 import torch

@@ -61,9 +61,19 @@ def _maybe_ddp(net, cfg, rank):
     # hollow_networks.py:690-712); without the flag their bucket never reduces and the second step raises
     # (the reference passes device_ids=[rank]; the device the parameters live on is the same thing on one node with one
     # process per GPU, and stays right when ranks and device indices differ -- several nodes, or ranks sharing a GPU)
-    unused = net.__class__.__name__ == "BidirectionalTransformer2" or bool(getattr(cfg, "ddp_find_unused_parameters", False))
+    hollow = net.__class__.__name__ == "BidirectionalTransformer2"
+    unused = hollow or bool(getattr(cfg, "ddp_find_unused_parameters", False))
+    # Bucket size.  The hollow transformer's backward is one autograd Function per block: 25 MB buckets reduce while the
+    # earlier blocks still run (overlap).  The U-Net's hand-written backward is ONE Function whose weight gradients come out
+    # of a single table launch at its end, so every hook fires at once and nothing is left to overlap with:
+    # there the whole gradient goes as ONE bucket -- one large all-reduce instead of three back-to-back ones (xGMI links are
+    # point-to-point; fewer, larger collectives amortise their start-up).  cfg.ddp_bucket_cap_mb overrides.
+    cap = getattr(cfg, "ddp_bucket_cap_mb", None)
+    if cap is None:
+        nbytes = sum(p.numel() * p.element_size() for p in net.parameters() if p.requires_grad)
+        cap = 25 if hollow else max(25, int(nbytes / 2 ** 20) + 8)
     return DDP(net, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()] if on_gpu else None,
-               find_unused_parameters=unused)
+               find_unused_parameters=unused, bucket_cap_mb=int(cap))
 
 
 def logistic_logits(mu, log_scale, S, fix_logistic, eps=1e-6):
