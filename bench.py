@@ -59,6 +59,7 @@ def parse():
                     help="time the data-parallel TRAINING step instead (MNIST tauLDR CT-ELBO, 64 samples per GPU, DDP over RCCL)")
     ap.add_argument("--engine-streams", type=int, default=None, help="sub-batches of the U-Net engine on parallel streams")
     ap.add_argument("--model-opt", action="append", default=[], help="integer engine option, key=value (tuning sweeps)")
+    ap.add_argument("--sampler-opt", action="append", default=[], help="integer sampler option, key=value (tuning sweeps)")
     return ap.parse_args()
 
 
@@ -192,6 +193,7 @@ def fp32_parity_mode(cfg, model, sampler, batch, steps=6, warmup=2):
             sampler.advance(st, i)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        del st
     finally:
         cfg.model.engine_precision, model._engine = prev_prec, prev_eng
     return {"value": round(batch * steps / el, 2), "unit": "sample-steps/s", "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
@@ -483,6 +485,9 @@ def main():
     for kv in a.model_opt:                     # e.g. --model-opt ring_min_tiles=160
         k_, v_ = kv.split("=")
         setattr(cfg.model, k_, int(v_))
+    for kv in a.sampler_opt:                   # e.g. --sampler-opt pipeline_sub_batches=1
+        k_, v_ = kv.split("=")
+        setattr(cfg.sampler, k_, int(v_))
     sampler.seed = 42
     sampler.rank_stream = rank              # distinct Philox key per rank; no data-path collective
     K, W = a.steps, a.warmup
@@ -507,6 +512,12 @@ def main():
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
+        if rank == 0 and getattr(st, "parts", 1) > 1:
+            # the roofline launches are timed one by one on the whole batch: a joined state advanced to the same step
+            st = sampler.begin(model, a.batch, pipeline=False)
+            for i in range(W + K):
+                sampler.advance(st, i)
+            torch.cuda.synchronize()
         roof = kernel_roofline(sampler, st, range(W + K, min(W + K + 20, sampler.num_steps - 1)), a.batch) if rank == 0 else None
         # the same kernel mid-trajectory (t ~ 0.5: fewer dimensions jump than next to t = 1, where the timed steps run)
         mid = sampler.num_steps // 2

@@ -576,7 +576,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
 // (double-buffered, one barrier per tap).  The next slab is prefetched into registers under the
 // last taps.  4 waves, each WM rows x (32*BNT) columns; grid.z splits the channel chunks when M
 // is too small to fill the chip (7x7 levels), partial sums meet in acc_buf.
-template <int BK, int BNT, int WM, bool EXT = false>
+// ALLTAPS (the 32-column tiles of the small levels, 7x7 / 4x4): all NINE taps' weight tiles of a channel chunk are staged
+// together with its slab -- one barrier pair and one round of global loads per chunk instead of one per tap.  With a
+// [32][BK] weight tile per tap the per-tap version spent a global-load latency (~1.5k cycles) on every 4 matrix
+// instructions: a 7x7 convolution of 128 samples ran at 6 % of the matrix pipe.
+template <int BK, int BNT, int WM, bool EXT = false, bool ALLTAPS = false>
 __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   constexpr int BN = 32 * BNT, BMP = 4 * WM, MT = WM / 32;
   constexpr int LDK = BK + 8, VPR = BK / 8;
@@ -584,6 +588,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   constexpr int PVMAX = ((BMP + 2 * 34) * VPR + 255) / 256;     // W <= 33
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CTDD_PATCH_STAMPS
+  unsigned long long pst[8];
+  int psi = 0;
+#define PSTAMP() { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (psi < 8) pst[psi++] = t_; }
+#else
+#define PSTAMP()
+#endif
+  PSTAMP()
   const int li = lane & 31, g = lane >> 5;
   const int HW = a.H * a.W, Wd = a.W;
   const int64_t M = (int64_t)a.B * HW;
@@ -592,7 +604,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   const int halo = Wd + 1;
   const int PR = BMP + 2 * halo;                                // slab rows
   unsigned short* Ap = (unsigned short*)smem;                   // [PR][LDK]
-  unsigned short* Bs = Ap + (size_t)PR * LDK;                   // [2][BN][LDK]
+  unsigned short* Bs = Ap + (size_t)PR * LDK;                   // [2][BN][LDK]   (ALLTAPS: [9][BN][LDK])
+  constexpr int NRB = ALLTAPS ? 9 * BV : BV;
   const int npv = PR * VPR;                                     // slab vectors
 
   // output pixel of this lane in every row tile: (y, x, in range)
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   for (int sgi = 0; sgi < a.nseg; ++sgi) nunits += a.seg[sgi].C / BK;
   const int zs = blockIdx.z, nz = a.ksplit > 1 ? a.ksplit : 1;
 
-  uint4 rp[PVMAX], rb[BV];
+  uint4 rp[PVMAX], rb[NRB];
   auto unit_info = [&](int u, int& sgi, int& c0, int& kbase) {   // kbase = K offset of (segment, tap 0, c0)
     int k = 0;
     sgi = 0;
@@ -650,6 +663,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
       rb[i] = ok ? *(const uint4*)(a.w_hi + (size_t)(n0 + n) * a.Ktot + koff + (v % VPR) * 8) : make_uint4(0, 0, 0, 0);
     }
   };
+  auto load_b_all = [&](int kb, int C, int ntap_) {             // ALLTAPS: the weight tiles of every tap of one chunk
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int i = 0; i < BV; ++i) {
+        const int v = tid + 256 * i;
+        const int n = v / VPR;
+        const bool ok = tp < ntap_ && v < BN * VPR && n0 + n < a.N;
+        if (ALLTAPS)
+          rb[(ALLTAPS ? tp : 0) * BV + i] = ok ? *(const uint4*)(a.w_hi + (size_t)(n0 + n) * a.Ktot + kb + tp * C + (v % VPR) * 8) : make_uint4(0, 0, 0, 0);
+      }
+  };
+  auto store_b_all = [&](int ntap_) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int i = 0; i < BV; ++i) {
+        const int v = tid + 256 * i;
+        if (ALLTAPS && tp < ntap_ && v < BN * VPR)
+          *(uint4*)(Bs + ((size_t)tp * BN + v / VPR) * LDK + (v % VPR) * 8) = rb[(ALLTAPS ? tp : 0) * BV + i];
+      }
+  };
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
@@ -671,7 +706,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   if (u < nunits) {
     unit_info(u, sgi, c0, kbase);
     load_patch(sgi, c0);
-    load_b(kbase);
+    if (ALLTAPS) load_b_all(kbase, a.seg[sgi].C, a.seg[sgi].kind == SEG_1x1 ? 1 : 9);
+    else load_b(kbase);
   }
   int bbuf = 0;
   while (u < nunits) {
@@ -681,16 +717,61 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
     const int hl = one ? 0 : halo;
     __syncthreads();                       // previous unit's slab and weight tiles are out of use
     store_patch();
-    store_b(bbuf);
+    if (ALLTAPS) store_b_all(ntap);
+    else store_b(bbuf);
     __syncthreads();
+    PSTAMP()
     const int un = u + nz;                 // next unit of this slice
     int nsgi = 0, nc0 = 0, nkbase = 0;
     if (un < nunits) unit_info(un, nsgi, nc0, nkbase);
+    if (ALLTAPS && un < nunits) {          // next chunk's slab and all its weight tiles: in flight under this chunk's taps
+      load_patch(nsgi, nc0);
+      load_b_all(nkbase, a.seg[nsgi].C, a.seg[nsgi].kind == SEG_1x1 ? 1 : 9);
+    }
+    if constexpr (ALLTAPS && BNT == 1 && MT == 1) {
+      // straight-line chunk: 9 taps x BK/16 K-steps (or BK/16 for a 1x1 segment), the fragments of step i+1 requested from
+      // LDS before the matrix instruction of step i issues (with one MFMA per fragment pair a rolled tap loop exposed the
+      // LDS latency on every instruction)
+      constexpr int KS = BK / 16;
+      const unsigned short* A0 = Ap + (size_t)(hl + wave * WM + li) * LDK + g * 8;
+      const unsigned short* B0 = Bs + (size_t)li * LDK + g * 8;
+      constexpr int DEPTH = 4;            // fragment pairs in flight: ~128 cycles of LDS latency / 32 cycles per matrix instruction
+      uint4 fa[DEPTH], fb[DEPTH];
+      auto fetch = [&](int tap_, int ks_, int buf_) {
+        const int dy = one ? 1 : tap_ / 3, dx = one ? 1 : tap_ % 3;
+        const int shift = (dy - 1) * Wd + (dx - 1);
+        const bool okk = oin[0] && (unsigned)(oy[0] + dy - 1) < (unsigned)a.H && (unsigned)(ox[0] + dx - 1) < (unsigned)Wd;
+        uint4 raw = *(const uint4*)(A0 + (ptrdiff_t)shift * LDK + ks_ * 16);
+        if (!okk) raw = make_uint4(0, 0, 0, 0);
+        fa[buf_] = raw;
+        fb[buf_] = *(const uint4*)(B0 + (size_t)tap_ * BN * LDK + ks_ * 16);
+      };
+      if (one) {
+        static_assert(KS <= DEPTH, "1x1 chunk: all K-steps in flight at once");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fetch(0, ks, ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks]), __builtin_bit_cast(bf16x8, fb[ks]), acc[0][0], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) fetch(i / KS, i % KS, i);
+#pragma unroll
+        for (int i = 0; i < 9 * KS; ++i) {
+          const bf16x8 af_ = __builtin_bit_cast(bf16x8, fa[i % DEPTH]), bf_ = __builtin_bit_cast(bf16x8, fb[i % DEPTH]);
+          if (i + DEPTH < 9 * KS) fetch((i + DEPTH) / KS, (i + DEPTH) % KS, i % DEPTH);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_, bf_, acc[0][0], 0, 0, 0);
+        }
+      }
+    } else
     for (int tap = 0; tap < ntap; ++tap) {
+      if (ALLTAPS) bbuf = tap;
       // prefetch: next tap's weight tile, or (at the last tap) the next unit's first one + its slab
-      if (tap + 1 < ntap) load_b(kbase + (tap + 1) * sg.C);
-      else if (un < nunits) load_b(nkbase);
-      if (tap == (ntap > 4 ? 4 : 0) && un < nunits) load_patch(nsgi, nc0);
+      if (!ALLTAPS) {
+        if (tap + 1 < ntap) load_b(kbase + (tap + 1) * sg.C);
+        else if (un < nunits) load_b(nkbase);
+        if (tap == (ntap > 4 ? 4 : 0) && un < nunits) load_patch(nsgi, nc0);
+      }
       const int dy = one ? 1 : tap / 3, dx = one ? 1 : tap % 3;
       const int shift = (dy - 1) * Wd + (dx - 1);
       bool ok[MT];
@@ -716,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
             acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf, acc[mt][t], 0, 0, 0);
         }
       }
-      if (tap + 1 < ntap) {
+      if (!ALLTAPS && tap + 1 < ntap) {
         store_b(bbuf ^ 1);                 // the other buffer was last read before the previous barrier
         __syncthreads();
         bbuf ^= 1;
@@ -725,11 +806,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
     u = un; sgi = nsgi; c0 = nc0; kbase = nkbase;
   }
 
+  PSTAMP()
   const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
   if (!ts.lds) __syncthreads();
   float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
   conv_epilogue_rows<BNT, MT, EXT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
+  PSTAMP()
   tile_stats_flush(a, ts);
+  PSTAMP()
+#ifdef CTDD_PATCH_STAMPS
+  if (lane == 0 && a.acc_buf) {
+    unsigned long long* o = (unsigned long long*)a.acc_buf + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = i < psi ? pst[i] : 0;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ resident-weights patch convolution
@@ -1611,6 +1701,61 @@ __global__ __launch_bounds__(256) void k_rows_linear(const float* __restrict__ x
   }
 }
 
+// Every sample at the SAME time (all the samplers: t * ones((N,)), sampling.py:119-121): the whole time path -- sinusoid ->
+// W1 -> swish -> W2 -> swish -> this workgroup's 64 columns of all the ResBlock projections -- in ONE launch for one row.
+// Each workgroup recomputes the two hidden layers (74 k multiply-adds) instead of waiting on two more launches: the three
+// row-blocked launches above are latency chains of ~80 us at the head of every forward, this is one of ~10.
+__global__ __launch_bounds__(256) void k_time_uniform(const TimeArgs a, const float* __restrict__ proj_w, const float* __restrict__ proj_b,
+                                                      int Ntot, float* __restrict__ proj_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // e[ch] | hid[tdim] | act[tdim] | part[4][64]
+  float* e = sm;
+  float* hid = e + a.ch;
+  float* act = hid + a.tdim;
+  float* part = act + a.tdim;
+  const float t = a.t[0];
+  const int half = a.ch / 2;
+  for (int c = threadIdx.x; c < a.ch; c += 256) {
+    const int j = c < half ? c : c - half;
+    const float f = expf((float)j * (-logf(10000.0f) / (float)(half - 1)));
+    e[c] = c < half ? sinf(t * f) : cosf(t * f);
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.tdim; n += 256) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int i = 0; i < a.ch; i += 4) {
+      s0 = fmaf(a.w1[(size_t)i * a.tdim + n], e[i], s0); s1 = fmaf(a.w1[(size_t)(i + 1) * a.tdim + n], e[i + 1], s1);
+      s2 = fmaf(a.w1[(size_t)(i + 2) * a.tdim + n], e[i + 2], s2); s3 = fmaf(a.w1[(size_t)(i + 3) * a.tdim + n], e[i + 3], s3);
+    }
+    const float v = a.b1[n] + ((s0 + s1) + (s2 + s3));
+    hid[n] = v / (1.0f + expf(-v));
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < a.tdim; n += 256) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < a.tdim; i += 4) {
+      s0 = fmaf(a.w2[(size_t)i * a.tdim + n], hid[i], s0); s1 = fmaf(a.w2[(size_t)(i + 1) * a.tdim + n], hid[i + 1], s1);
+      s2 = fmaf(a.w2[(size_t)(i + 2) * a.tdim + n], hid[i + 2], s2); s3 = fmaf(a.w2[(size_t)(i + 3) * a.tdim + n], hid[i + 3], s3);
+    }
+    const float v = a.b2[n] + ((s0 + s1) + (s2 + s3));
+    act[n] = v / (1.0f + expf(-v));
+  }
+  __syncthreads();
+  const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + col, nc = n < Ntot ? n : Ntot - 1;
+  const int kq = a.tdim / 4, k0 = ks * kq;
+  float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 4
+  for (int i = k0; i < k0 + kq; i += 2) {
+    s0 = fmaf(proj_w[(size_t)i * Ntot + nc], act[i], s0);
+    s1 = fmaf(proj_w[(size_t)(i + 1) * Ntot + nc], act[i + 1], s1);
+  }
+  part[ks * 64 + col] = s0 + s1;
+  __syncthreads();
+  if (threadIdx.x < 64 && n < Ntot)
+    proj_out[n] = ((proj_b[n] + part[col]) + part[64 + col]) + (part[128 + col] + part[192 + col]);
+}
+
 // ------------------------------------------------------------------ mid-block self-attention (unet.py:152-200)
 // qkv: [B][T][3*C] fp32 with the reference's per-head channel order [q(ch) | k(ch) | v(ch)] per head;
 // one workgroup per (b, head): w = softmax((q s)^T (k s)), s = ch^-1/4 ; out[b][t][head*ch + c].
@@ -1633,19 +1778,29 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a) {
     w[i] = d;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < T; t += 256) {
+  // softmax rows: four neighbouring lanes per row (one thread per row left 200 of the 256 threads idle through three serial
+  // passes of T exps), the normalisation folded into the output pass below
+  float* rz = w + T * T;                                        // [T] 1 / row sum
+  for (int t4 = threadIdx.x; t4 < ((T + 63) / 64) * 256; t4 += 256) {
+    const int t = t4 >> 2, l4 = t4 & 3;
     float m = -INFINITY;
-    for (int s = 0; s < T; ++s) m = fmaxf(m, w[t * T + s]);
+    if (t < T)
+      for (int s = l4; s < T; s += 4) m = fmaxf(m, w[t * T + s]);
+    m = fmaxf(m, __shfl_xor(m, 1, WAVE));
+    m = fmaxf(m, __shfl_xor(m, 2, WAVE));
     float z = 0.0f;
-    for (int s = 0; s < T; ++s) { const float e = expf(w[t * T + s] - m); w[t * T + s] = e; z += e; }
-    const float iz = 1.0f / z;
-    for (int s = 0; s < T; ++s) w[t * T + s] *= iz;
+    if (t < T)
+      for (int s = l4; s < T; s += 4) { const float e = expf(w[t * T + s] - m); w[t * T + s] = e; z += e; }
+    z += __shfl_xor(z, 1, WAVE);
+    z += __shfl_xor(z, 2, WAVE);
+    if (t < T && l4 == 0) rz[t] = 1.0f / z;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < T * ch; i += 256) {
     const int t = i / ch, c = i % ch;
     float o = 0.0f;
     for (int s = 0; s < T; ++s) o = fmaf(w[t * T + s], v[s * ch + c], o);
+    o *= rz[t];
     const size_t oo = ((size_t)b * T + t) * a.C + hd * ch + c;
     if (a.out_hi) a.out_hi[oo] = to_bf16(o);
     if (a.out_f32) a.out_f32[oo] = o;
@@ -1731,18 +1886,18 @@ extern "C" int ctdd_unet_conv(const void* args_, int bk, int bnt, int f32, void*
   CTDD_REQUIRE(false, CTDD_ERANGE, "no conv instantiation for BK=%d BNT=%d", bk, bnt);
 }
 
-template <int BK, int BNT, int WM, bool EXT = false>
+template <int BK, int BNT, int WM, bool EXT = false, bool ALLTAPS = false>
 static int launch_patch(const ConvArgs& a, hipStream_t st) {
   constexpr int LDK = BK + 8;
   const int PR = 4 * WM + 2 * (a.W + 1);
-  size_t lds = ((size_t)PR + 2 * 32 * BNT) * LDK * 2;
+  size_t lds = ((size_t)PR + (ALLTAPS ? 9 : 2) * 32 * BNT) * LDK * 2;
   const size_t epi_lds = epilogue_rows_lds(4, BNT, 4 * WM, a.H * a.W);
   if (lds < epi_lds) lds = epi_lds;
   const int64_t M = (int64_t)a.B * a.H * a.W;
   dim3 g((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), a.ksplit > 1 ? a.ksplit : 1);
   static bool attr_done[16] = {};
-  ensure_lds_ceiling((const void*)k_conv_patch<BK, BNT, WM, EXT>, attr_done);
-  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM, EXT>), g, dim3(256), lds, st, a);
+  ensure_lds_ceiling((const void*)k_conv_patch<BK, BNT, WM, EXT, ALLTAPS>, attr_done);
+  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM, EXT, ALLTAPS>), g, dim3(256), lds, st, a);
   if (int rc = finish_launch("k_conv_patch")) return rc;
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
@@ -1770,6 +1925,10 @@ extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, 
     CASEX(64, 4) CASEX(64, 2) CASEX(64, 1) CASEX(48, 4) CASEX(48, 3) CASEX(48, 2) CASEX(48, 1) CASEX(32, 4) CASEX(32, 3) CASEX(32, 1) CASEX(16, 1)
 #undef CASEX
     CTDD_REQUIRE(false, CTDD_ERANGE, "no patch-conv instantiation with activation / split output for BK=%d BNT=%d WM=%d (wm must be 32)", bk, bnt, wm);
+  }
+  if (bnt == 1 && wm == 32 && a.ksplit <= 1) {  // 32-column tiles (the small levels): every tap's weight tile staged per chunk
+    if (bk == 64) return launch_patch<64, 1, 32, false, true>(a, st);
+    if (bk == 48) return launch_patch<48, 1, 32, false, true>(a, st);
   }
 #define CASEP(BK_, BNT_, WM_) if (bk == BK_ && bnt == BNT_ && wm == WM_) return launch_patch<BK_, BNT_, WM_>(a, st);
   CASEP(48, 3, 64) CASEP(48, 3, 32) CASEP(48, 4, 64) CASEP(48, 4, 32)
@@ -1939,10 +2098,19 @@ extern "C" int ctdd_unet_time(const void* args_, const float* proj_w, const floa
   return finish_launch("k_rows_linear");
 }
 
+extern "C" int ctdd_unet_time_uniform(const void* args_, const float* proj_w, const float* proj_b, int Ntot, float* proj_out,
+                                      void* stream) {
+  const TimeArgs& a = *(const TimeArgs*)args_;
+  CTDD_REQUIRE(a.t && a.tdim % 16 == 0 && a.ch % 16 == 0 && Ntot > 0, CTDD_EINVAL, "bad time arguments");
+  const size_t lds = (size_t)(a.ch + 2 * a.tdim + 256) * sizeof(float);
+  hipLaunchKernelGGL(k_time_uniform, dim3((Ntot + 63) / 64), dim3(256), lds, (hipStream_t)stream, a, proj_w, proj_b, Ntot, proj_out);
+  return finish_launch("k_time_uniform");
+}
+
 extern "C" int ctdd_unet_attention(const void* args_, void* stream) {
   const AttnArgs& a = *(const AttnArgs*)args_;
   const int ch = a.C / a.heads;
-  const size_t lds = (size_t)(3 * a.T * ch + a.T * a.T) * sizeof(float);
+  const size_t lds = (size_t)(3 * a.T * ch + a.T * a.T + a.T) * sizeof(float);
   CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "attention tile too large (T=%d)", a.T);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)k_attn_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

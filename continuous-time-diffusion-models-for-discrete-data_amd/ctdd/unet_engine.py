@@ -69,7 +69,8 @@ def _lib():
         for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_patch", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_res", [_P, _I, _P]), ("ctdd_unet_conv_ring", [_P, _I, _P]),
                            ("ctdd_unet_upsample2x", [_P, _I, _I, _I, _I, _P, _P]), ("ctdd_unet_first_conv", [_P, _P]),
                            ("ctdd_unet_gn_apply", [_P, _P]), ("ctdd_unet_channel_stats", [_P, _I, _I, _I, _P, _P]),
-                           ("ctdd_unet_time", [_P, _P, _P, _I, _P, _P]), ("ctdd_unet_attention", [_P, _P]),
+                           ("ctdd_unet_time", [_P, _P, _P, _I, _P, _P]), ("ctdd_unet_time_uniform", [_P, _P, _P, _I, _P, _P]),
+                           ("ctdd_unet_attention", [_P, _P]),
                            ("ctdd_unet_logistic_head", [_P, _P])):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argt, _I
@@ -164,7 +165,7 @@ class UNetEngine:
         self._stats_off += n
         return off
 
-    def _build(self, B, x_dtype, logits_out=None, tc=None, logits_bf16=False):
+    def _build(self, B, x_dtype, logits_out=None, tc=None, logits_bf16=False, uniform_t=False):
         net, m = self.net, self.cfg.model
         lib = _lib()
         dev = self.dev
@@ -317,7 +318,7 @@ class UNetEngine:
             else:
                 bk = pick_bk(cs)
                 bnt = pick_bnt(N, bk)
-                if (not self.precise) and -(-M_ // 128) * -(-N // (32 * bnt)) < 64 and bk in (96, 64, 32):
+                if (not self.precise) and -(-M_ // 128) * -(-N // (32 * bnt)) < int(getattr(m, "igemm_small_wgs", 256)) and bk in (96, 64, 32):
                     bnt = 1                                        # tiny grids: 32-column tiles, more workgroups
                 launch(lib.ctdd_unet_conv, C.byref(a), bk, bnt, int(self.precise), label=lab + f" igemm bk={bk} bnt={bnt}", flops=2 * M_ * N * Ktot)
 
@@ -350,7 +351,11 @@ class UNetEngine:
         pb = torch.cat([rb.time[1].bias.detach().float() for rb in resblocks], 0).contiguous()
         Ntot = pw.shape[1]
         st.tact = torch.empty((B, tdim), dtype=torch.float32, device=dev)
-        st.tproj = torch.empty((B, Ntot), dtype=torch.float32, device=dev)
+        uniform_t = bool(uniform_t) and tc is None
+        # uniform_t: every sample at the same time (the samplers): ONE projection row from one fused launch, read by the
+        # convolutions with a zero batch stride (csrc/unet_kernels.hip: k_time_uniform)
+        st.tproj = torch.empty((1 if uniform_t else B, Ntot), dtype=torch.float32, device=dev)
+        tb_stride = 0 if uniform_t else Ntot
         ta = _TimeArgs()
         tw = [net.time[1].weight.t(), net.time[1].bias, net.time[3].weight.t(), net.time[3].bias]      # weights as [in][out]
         tw = [w.detach().float().contiguous() for w in tw]
@@ -359,7 +364,7 @@ class UNetEngine:
         ta.w1, ta.b1, ta.w2, ta.b2, ta.hid, ta.act = ptr(tw[0]), ptr(tw[1]), ptr(tw[2]), ptr(tw[3]), ptr(st.thid), ptr(st.tact)
         keep.extend(tw + [pw, pb, ta])
         if tc is None:
-            launch(lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
+            launch(lib.ctdd_unet_time_uniform if uniform_t else lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
         else:
             tc.tproj, tc.resblocks = st.tproj, resblocks          # filled by the caller before the plan runs
         toff = {}
@@ -399,7 +404,7 @@ class UNetEngine:
             h = _Tensor(self, B, Hc, Wc, cout)
             b1 = rb.conv1.bias.detach().float().contiguous()
             conv([(a1, a1.C, SEG_3x3)], [(rb.conv1.weight, 0)], b1, cout, Hc, Wc,
-                 Hc, Wc, h, tb=(st.tproj.data_ptr() + 4 * toff[id(rb)], Ntot), bias_params=[rb.conv1.bias])
+                 Hc, Wc, h, tb=(st.tproj.data_ptr() + 4 * toff[id(rb)], tb_stride), bias_params=[rb.conv1.bias])
             drop = float(rb.dropout.p) if (tc is not None and tc.dropout) else 0.0
             a2 = gn_apply([h], rb.norm2, True, rb.norm2.eps, Hc * Wc, drop_p=drop)
             y = _Tensor(self, B, Hc, Wc, cout)
@@ -535,9 +540,9 @@ class UNetEngine:
         for step in st.plan:
             step()
 
-    def _prepare(self, B, x_dtype, x, times, logits_out=None, logits_bf16=False):
+    def _prepare(self, B, x_dtype, x, times, logits_out=None, logits_bf16=False, uniform_t=False):
         """Build, warm up and capture the plan for (B, dtype)."""
-        st = self._build(B, x_dtype, logits_out, logits_bf16=logits_bf16)
+        st = self._build(B, x_dtype, logits_out, logits_bf16=logits_bf16, uniform_t=uniform_t)
         st.x_in.copy_(x.reshape(st.x_in.shape))
         st.t_in.copy_(times.float())
         self._run_plan(st)                    # eager warm-up (also sets the LDS attributes)
@@ -568,10 +573,15 @@ class UNetEngine:
                 pass
             raise native.CtddError("eager replay goes through _run_plan")
 
-    def __call__(self, x, times, logits_bf16=False):
-        """logits_bf16: write the (B, D, S) logits in bf16 (bf16 engine with the `logits` head; ignored otherwise)."""
+    def __call__(self, x, times, logits_bf16=False, uniform_time=False, slot=None):
+        """logits_bf16: write the (B, D, S) logits in bf16 (bf16 engine with the `logits` head; ignored otherwise).
+        uniform_time: the caller guarantees that every entry of `times` is the same value (the sampler loops): the time path
+        runs once, as one launch, for times[0].
+        slot: the caller drives several INDEPENDENT sub-batches itself, each on its own stream (TauL's pipelined loop): plan
+        `slot` has buffers of its own and replays on the caller's current stream, with no sub-batch split in here."""
         B = x.shape[0]
         lb = bool(logits_bf16) and not self.precise and self.cfg.model.model_output == "logits"
+        ut = bool(uniform_time)
         ver = self._weights_version()
         if ver != self._wver:                     # weights changed (optimizer step, EMA swap): re-pack
             self._plans.clear()
@@ -580,9 +590,9 @@ class UNetEngine:
             raise native.CtddError(f"UNetEngine expects integer states, got {x.dtype}")
         # Sub-batches on parallel streams: samples are independent, and two half-size forwards in flight fill the
         # CUs that one forward leaves idle (half-empty last rounds of the 392-tile grids, 98-workgroup 7x7 levels).
-        nsub = int(getattr(self.cfg.model, "engine_streams", 2))
+        nsub = int(getattr(self.cfg.model, "engine_streams", 2)) if slot is None else 1
         if nsub > 1 and B % nsub == 0 and B // nsub >= 32 and getattr(self.cfg.model, "engine_graph", True):
-            key = (B, x.dtype, nsub, lb)
+            key = (B, x.dtype, nsub, ut, lb)
             grp = self._plans.get(key)
             Bs = B // nsub
             xs = x.reshape(B, -1)
@@ -590,7 +600,7 @@ class UNetEngine:
                 C_, H_, W_ = self.cfg.data.shape
                 logits = torch.empty((B, C_ * H_ * W_, self.net.S), dtype=torch.bfloat16 if lb else torch.float32, device=self.dev)
                 subs = [self._prepare(Bs, x.dtype, xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs], logits[i * Bs:(i + 1) * Bs],
-                                      logits_bf16=lb) for i in range(nsub)]
+                                      logits_bf16=lb, uniform_t=ut) for i in range(nsub)]
                 grp = self._plans[key] = (logits, subs, [torch.cuda.Stream(device=self.dev) for _ in range(nsub - 1)])
             logits, subs, streams = grp
             if all(s.graph is not None for s in subs):
@@ -609,10 +619,10 @@ class UNetEngine:
                 for ev in done:
                     main.wait_event(ev)
                 return logits
-        key = (B, x.dtype, lb)
+        key = (B, x.dtype, ut, lb) if slot is None else (B, x.dtype, "slot", int(slot), ut, lb)
         st = self._plans.get(key)
         if st is None:
-            st = self._plans[key] = self._prepare(B, x.dtype, x, times, logits_bf16=lb)
+            st = self._plans[key] = self._prepare(B, x.dtype, x, times, logits_bf16=lb, uniform_t=ut)
         st.x_in.copy_(x.reshape(st.x_in.shape))
         st.t_in.copy_(times.float())
         if st.graph is not None:

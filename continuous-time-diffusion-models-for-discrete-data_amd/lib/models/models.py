@@ -34,20 +34,25 @@ class borrow_engine_output:
     """`with borrow_engine_output(model):` -- inside, model(x, t) returns the engine plan's own logits buffer
     (no copy); the next forward overwrites it.  The sampler loops consume logits within a step and use this."""
 
-    def __init__(self, model, bf16_logits=False):
+    def __init__(self, model, bf16_logits=False, uniform_time=False):
         """bf16_logits: the U-Net engine's output convolution writes (B, D, S) logits in bf16 (bf16 engine, `logits` head only;
-        any other model ignores the request and returns fp32) -- what the S = 256 bf16 step kernel reads."""
+        any other model ignores the request and returns fp32) -- what the S = 256 bf16 step kernel reads.
+        uniform_time: a PROMISE of the caller that every forward inside passes one time value for the whole batch
+        (`t * ones((N,))`, as every sampler does): the U-Net engine then runs its time path once for times[0]."""
         self.model = model
         self.bf16_logits = bool(bf16_logits)
+        self.uniform_time = bool(uniform_time)
 
     def __enter__(self):
-        self.prev = (getattr(self.model, "_borrow_engine_output", False), getattr(self.model, "_engine_logits_bf16", False))
+        self.prev = (getattr(self.model, "_borrow_engine_output", False), getattr(self.model, "_engine_logits_bf16", False),
+                     getattr(self.model, "_engine_uniform_time", False))
         self.model._borrow_engine_output = True
         self.model._engine_logits_bf16 = self.bf16_logits
+        self.model._engine_uniform_time = self.uniform_time
         return self.model
 
     def __exit__(self, *exc):
-        self.model._borrow_engine_output, self.model._engine_logits_bf16 = self.prev
+        self.model._borrow_engine_output, self.model._engine_logits_bf16, self.model._engine_uniform_time = self.prev
         return False
 
 
@@ -178,7 +183,8 @@ class ImageX0PredBasePaul(nn.Module):
                 finally:
                     inner._engine_hook = None
             return self._engine.train_forward(x, times)
-        out = self._engine(x, times, logits_bf16=bool(getattr(self, "_engine_logits_bf16", False)))
+        out = self._engine(x, times, logits_bf16=bool(getattr(self, "_engine_logits_bf16", False)),
+                           uniform_time=bool(getattr(self, "_engine_uniform_time", False)), slot=getattr(self, "_engine_slot", None))
         # the plan owns its output buffer: hand out a copy unless the caller (a sampler loop that consumes the
         # logits before the next forward) asked to borrow it -- two live results must not alias
         return out if getattr(self, "_borrow_engine_output", False) else out.clone()

@@ -117,7 +117,7 @@ class _GridSampler:
         bf = (self.S == 256 and self._needs_qt0() and getattr(self.cfg.sampler, "fast_s256", True)
               and (self.branch == native.BRANCH_CTELBO or self.logit_type == "reverse_prob")
               and self._step_bf16(model) and bool(getattr(self.cfg.sampler, "logits_bf16", True)))
-        return borrow_engine_output(model, bf16_logits=bf)
+        return borrow_engine_output(model, bf16_logits=bf, uniform_time=True)      # (every sampler passes t * ones((N,)))
 
     @staticmethod
     def _net_logits(model, x, t, fast=None):
@@ -177,7 +177,19 @@ class TauL(_GridSampler):
 
     # The loop is split into begin / advance / finish so that a driver (bench.py, the multi-GPU
     # sharder) can time or interleave exact sampler steps; sample() is their composition.
-    def begin(self, model, N):
+    def _pipeline_parts(self, model, N):
+        """Independent sub-batches the loop drives on parallel streams (cfg.sampler.pipeline_sub_batches; default: the U-Net
+        engine's `engine_streams`, 2).  Samples never interact, so each sub-batch runs its own chain
+        forward -> fused step -> forward -> ... with NO join per step: one chain's tau-leap launch (vector ALU / memory) runs
+        under the other's convolutions (matrix cores) instead of on the critical path of both."""
+        p = getattr(self.cfg.sampler, "pipeline_sub_batches", None)
+        unet = hasattr(model, "_engine_forward") and getattr(self.cfg.model, "engine", "hip") == "hip" and str(model.device) != "cpu"
+        if p is None:
+            p = int(getattr(self.cfg.model, "engine_streams", 2)) if unet else 1
+        p = int(p)
+        return p if (unet and p > 1 and N % p == 0 and N // p >= 32) else 1
+
+    def begin(self, model, N, pipeline=None):
         dev = torch.device(model.device)
         st = type("TauLState", (), {})()
         st.model, st.N, st.dev, st.key = model, N, dev, self._key()
@@ -188,33 +200,64 @@ class TauL(_GridSampler):
         st.changed = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
         st.flags = native.STEP_ORDINAL if self.is_ordinal else 0
         st.sub = 1 + max(int(self.num_corrector_steps), 0)
+        st.parts = self._pipeline_parts(model, N) if pipeline is None else (int(pipeline) if pipeline else 1)
+        if st.parts > 1:
+            P = st.parts
+            n = N // P
+            st.xs = [st.x[j * n:(j + 1) * n].clone() for j in range(P)]
+            st.x = None                                     # (joined again by finish / state_x)
+            st.changed_p = torch.zeros((P, self.num_steps), dtype=torch.int32, device=dev)
+            main = torch.cuda.current_stream(dev)
+            st.streams = [main] + [torch.cuda.Stream(device=dev) for _ in range(P - 1)]
+            for s_ in st.streams[1:]:
+                s_.wait_stream(main)                        # tables, initial state and plans' weights are ready
         return st
+
+    def state_x(self, st):
+        """The current state (N, D) of all samples (joins the sub-batch streams when the loop is pipelined)."""
+        if st.parts == 1:
+            return st.x
+        main = st.streams[0]
+        for s_ in st.streams[1:]:
+            main.wait_stream(s_)
+        return torch.cat(st.xs, 0)
 
     def advance(self, st, i):
         """Step i of the grid: network forward, fused reverse-rate/jump/update launch, correctors."""
         with self._borrow(st.model):
-            self._advance(st, i)
+            if st.parts == 1:
+                st.x = self._advance_one(st, i, st.x, st.N, st.key, st.changed[i:i + 1])
+                return
+            model = st.model
+            try:
+                for j in range(st.parts):
+                    with torch.cuda.stream(st.streams[j]):
+                        model._engine_slot = j
+                        # a Philox key per sub-batch (the rows of a launch are numbered from 0)
+                        st.xs[j] = self._advance_one(st, i, st.xs[j], st.N // st.parts, st.key + 7919 * j, st.changed_p[j, i:i + 1])
+            finally:
+                model._engine_slot = None
 
-    def _advance(self, st, i):
-        model, N = st.model, st.N
+    def _advance_one(self, st, i, x, N, key, changed):
+        model = st.model
         t = st.ts[i]
         h = float(np.float32(st.ts[i] - st.ts[i + 1]))
         t_ones = self._t_ones(st.t32, i, N, st.dev)
         q_i = st.qt0[i] if st.qt0 is not None else None
-        logits = self._net_logits(model, st.x, t_ones, st.fast)
-        st.x = self._leap(model, logits, st.x, q_i, st.fast, i, st.betas[i], h, st.flags, st.key, i * st.sub,
-                          changed=st.changed[i:i + 1])
+        logits = self._net_logits(model, x, t_ones, st.fast)
+        x = self._leap(model, logits, x, q_i, st.fast, i, st.betas[i], h, st.flags, key, i * st.sub, changed=changed)
         if t <= self.corrector_entry_time:
             for c in range(self.num_corrector_steps):
-                logits = self._net_logits(model, st.x, t_ones, st.fast)
-                st.x = self._leap(model, logits, st.x, q_i, st.fast, i, st.betas[i], h,
-                                  st.flags | native.STEP_CORRECTOR, st.key, i * st.sub + 1 + c)
+                logits = self._net_logits(model, x, t_ones, st.fast)
+                x = self._leap(model, logits, x, q_i, st.fast, i, st.betas[i], h, st.flags | native.STEP_CORRECTOR, key, i * st.sub + 1 + c)
+        return x
 
     def finish(self, st):
-        x = st.x
+        x = self.state_x(st)
+        changed = st.changed if st.parts == 1 else st.changed_p.sum(0)
         if self.loss_name in ("CTElbo", "NLL"):
             x = self._final_argmax(st.model, x, st.N)
-        return x.cpu().numpy().astype(int), (st.changed.cpu().numpy() / st.N).tolist()
+        return x.cpu().numpy().astype(int), (changed.cpu().numpy() / st.N).tolist()
 
     def sample(self, model, N):
         with torch.no_grad(), self._borrow(model):
@@ -382,7 +425,7 @@ class ExactSampling(_GridSampler):
     def sample(self, model, N):
         dev = torch.device(model.device)
         key = self._key()
-        with torch.no_grad(), borrow_engine_output(model):
+        with torch.no_grad(), borrow_engine_output(model, uniform_time=True):
             x = self._initial(model, N, key, self.cfg.model.Q_sigma).long()
             ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
             pr = model.process

@@ -75,6 +75,9 @@ typedef struct {
 /* sinusoid -> Linear -> Swish -> Linear -> Swish, then every ResBlock's time projection (unet.py:223-241,332-337,110);
  * proj_w = the concatenated projection weights transposed to [tdim][Ntot] */
 int ctdd_unet_time(const void* time_args, const float* proj_w, const float* proj_b, int Ntot, float* proj_out, void* stream);
+/* the same for ONE time shared by every sample (the samplers pass t * ones((N,)), sampling.py:119-121): t[0] only, one launch,
+ * proj_out is a single row (Ntot) that the convolutions read with a zero batch stride */
+int ctdd_unet_time_uniform(const void* time_args, const float* proj_w, const float* proj_b, int Ntot, float* proj_out, void* stream);
 
 typedef struct { const float* qkv; int B, T, C, heads; void* out_hi; float* out_f32; } ctdd_attn_args;
 int ctdd_unet_attention(const void* attn_args, void* stream);              /* unet.py:176-200 */

@@ -215,4 +215,4 @@ def test_logprob_reverse_prob_matrix_core_path_matches_generic(S, D, B):
         g64, = torch.autograd.grad(obj, l64)
         assert float((g_new.cpu().double() - g64).abs().max()) < 5e-5 * float(g64.abs().max())
         if x0_ is not None:
-            np.testing.assert_allclose(float(ce_new), w * float(ce64), rtol=2e-5)     # (the kernels return the weighted term)
+            np.testing.assert_allclose(float(ce_new), w * float(ce64.detach()), rtol=2e-5)     # (the kernels return the weighted term)

@@ -196,3 +196,41 @@ def test_unet_model_samples_end_to_end():
     assert samples.shape == (8, 784) and samples.dtype.kind == "i"
     assert samples.min() >= 0 and samples.max() <= 255 and len(change_dim) == 5
     model.train()
+
+
+def test_taul_pipelined_sub_batches_match_the_joined_loop_in_law():
+    """TauL drives the U-Net's sub-batches as independent chains on parallel streams (cfg.sampler.pipeline_sub_batches; no join
+    per step): same network, same tables, a Philox key per sub-batch.  Against the joined loop (pipeline off) on the same
+    model: same per-step change rates within sampling error, same marginal state histogram (two-sample chi-square), and the
+    pipelined run itself is reproducible under a fixed seed."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    import lib.sampling.sampling  # noqa: F401
+    import lib.sampling.sampling_utils as su
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.sampler.num_steps = 12
+    torch.manual_seed(0)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    N = 64
+    smp = su.get_sampler(cfg)
+    smp.seed = 5
+    cfg.sampler.pipeline_sub_batches = 2
+    with torch.no_grad():
+        st = smp.begin(model, N)
+    assert st.parts == 2 and len(st.xs) == 2 and st.xs[0].shape == (32, 784)
+    a, ca = smp.sample(model, N)
+    a2, ca2 = smp.sample(model, N)
+    # fixed seed: the same Philox draws; the network's GroupNorm statistics meet in atomics whose order moves the last bits of
+    # the logits when plans run concurrently, so a few dimensions in ten thousand may take the other side of a comparison
+    assert (a != a2).mean() < 3e-3 and np.abs(np.asarray(ca) - np.asarray(ca2)).max() < 1.0
+    cfg.sampler.pipeline_sub_batches = 1
+    b, cb = smp.sample(model, N)
+    assert a.shape == b.shape == (N, 784) and len(ca) == len(cb) == 12
+    assert not np.array_equal(a[32:], b[32:])                       # (the second sub-batch draws from its own stream)
+    ca, cb = np.asarray(ca), np.asarray(cb)
+    assert np.abs(ca - cb).max() < 0.05 * 784 + 6 * np.sqrt(784 / N), (ca, cb)
+    chi, dof = _two_sample_chi2(a, b, 256)
+    assert chi < dof + 6 * np.sqrt(2 * dof), (chi, dof)
+    model.train()

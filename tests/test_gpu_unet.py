@@ -174,7 +174,7 @@ def _sub_batch_streams_case(cfg, model, B, iters=4):
             o2 = e2(x, t).clone()
             cfg.model.engine_streams = 1
             o1 = e1(x, t).clone()
-            assert any(len(k) == 4 for k in e2._plans) and all(len(k) == 3 for k in e1._plans)    # (B, dtype, streams, bf16 logits) / (B, dtype, bf16 logits)
+            assert any(len(k) == 5 for k in e2._plans) and all(len(k) == 4 for k in e1._plans)    # (B, dtype, streams, uniform t, bf16 logits) / (B, dtype, uniform t, bf16 logits)
             cfg.model.engine = "torch"
             ref = model(x.view(B, -1), t)
             cfg.model.engine = "hip"
@@ -317,3 +317,29 @@ def test_engine_bf16_logits_on_request():
         assert f32.dtype == torch.float32
         err = (b16 - f32).abs()
         assert (err <= f32.abs() * 2.0 ** -8 + 1e-6).all(), float((err / f32.abs().clamp_min(1e-3)).max())
+
+
+def test_engine_uniform_time_plan_matches_the_general_plan():
+    """borrow_engine_output(model, uniform_time=True): the one-launch time path for a batch that shares one time value
+    (k_time_uniform) gives the logits of the general three-launch path on the same inputs."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from lib.models.models import borrow_engine_output
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.device = "cuda"
+    torch.manual_seed(1)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for B, tval in ((5, 0.37), (64, 0.93)):
+        x = torch.randint(0, 256, (B, 784), device="cuda", generator=g)
+        t = torch.full((B,), tval, device="cuda")
+        with torch.no_grad():
+            general = model(x, t)
+            with borrow_engine_output(model, uniform_time=True):
+                uni = model(x, t).clone()
+        scale = float(general.abs().max())
+        # (the time path is fp32 in both plans and differs in summation order only; downstream the bf16 activations amplify
+        #  that to a few 1e-3 of the logit range -- the bf16 mode's own bar against the fp32 module is 5e-2)
+        assert float((uni - general).abs().max()) < 2e-2 * scale, float((uni - general).abs().max()) / scale

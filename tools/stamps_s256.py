@@ -32,7 +32,7 @@ def bench_regime(a):
     N, D = a.batch, 784
     nt = (N * D + 127) // 128
     with torch.no_grad():
-        st = sampler.begin(model, N)
+        st = sampler.begin(model, N, pipeline=False)
         done = 0
         for target in (5, 45, 500):
             for i in range(done, target):
