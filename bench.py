@@ -300,12 +300,14 @@ def baseline_configs():
     dev = torch.device("cuda")
     out = {}
 
-    def sample_rate(key, what, get_config, N, steps, **over):
+    def sample_rate(key, what, get_config, N, steps, model_over=None, **over):
         cfg = get_config()
         cfg.device = "cuda"
         cfg.sampler.num_steps = steps
         for k_, v_ in over.items():
             setattr(cfg.sampler, k_, v_)
+        for k_, v_ in (model_over or {}).items():
+            setattr(cfg.model, k_, v_)
         torch.manual_seed(0)
         model = mu.create_model(cfg, dev)
         model.eval()
@@ -348,7 +350,10 @@ def baseline_configs():
 
     sample_rate("cifar10_unet_taul", "config 5 sampler: CIFAR-10 tauLDR U-Net (D=3072, S=256, logistic head), TauL", c10, 64, 20)
     sample_rate("maze_hollow_midpoint", "config 4: maze hollow transformer (D=225, S=3), MidPointTauL", maze, 128, 50, name="MidPointTauL")
-    sample_rate("mnist_hollow_taul", "config 3 sampler: MNIST hollow transformer (D=784, S=256), TauL", hmnist, 32, 10, name="TauL")
+    sample_rate("mnist_hollow_taul", "config 3 sampler: MNIST hollow transformer (D=784, S=256), TauL; engine_precision bf16x3 (default: logits "
+                "within 4e-6 of the fp32 module's range, three bf16 products per contraction)", hmnist, 32, 10, name="TauL")
+    sample_rate("mnist_hollow_taul_bf16", "the same with engine_precision bf16 (single bf16 operands: logits within 2e-3 of the range; bf16 step kernel)",
+                hmnist, 32, 10, model_over={"engine_precision": "bf16"}, name="TauL")
     train_ms("mnist_hollow_catrmnll_train", "config 3: MNIST hollow transformer training step (CatRMNLL, reverse_prob logits)", hmnist,
              (1, 28, 28), 256, 32, loss_name="CatRMNLL")
     train_ms("cifar10_unet_ctelbolambda_train", "config 5: CIFAR-10 tauLDR U-Net training step (CTElboLambda)", c10, (3, 32, 32), 256, 32)

@@ -58,7 +58,8 @@ def _lib():
         for name, argt in (("ctdd_hollow_embed", [_P, _P]), ("ctdd_hollow_layernorm", [_P, _P]),
                            ("ctdd_hollow_add", [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _I64, _P]),
                            ("ctdd_hollow_put_rows", [_P, _P, _P, _P, _I64, _I, _I, _P]), ("ctdd_hollow_attention", [_P, _P]),
-                           ("ctdd_hollow_attention_bf16", [_P, _P]), ("ctdd_gemm_bf16", [_P, _P])):
+                           ("ctdd_hollow_attention_bf16", [_P, _P]), ("ctdd_gemm_bf16", [_P, _P]),
+                           ("ctdd_hollow_small_linear", [_P, _P, _P, _I, _I, _I, _I, _P, _P])):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argt, _I
         _sigs_done = True
@@ -86,6 +87,10 @@ class HollowEngine:
         # accumulation (x w ~ xh wh + xl wh + xh wl, dropped terms ~2^-17 relative): fp32-grade logits at bf16 matrix rates
         self.fast = self.precision in ("bf16", "bf16x3")
         self.split = self.precision == "bf16x3"
+        # model.engine_bf16_linears: names of linear layers ("fc1", "fc2", "qkv", "attn out", "resid 1", ...) that take ONE bf16
+        # product in the bf16x3 mode (their inputs' hi parts against the weights' hi parts): a third of their matrix work for a
+        # measured logit error between the two pure modes (tests/test_gpu_hollow.py states it per setting)
+        self.single = set(getattr(self.net.config.model, "engine_bf16_linears", ()) or ())
         self.dev = next(self.net.parameters()).device
         if self.dev.type != "cuda":
             raise native.CtddError("HollowEngine needs the model on a GPU")
@@ -133,6 +138,12 @@ class HollowEngine:
             w = W(lin_w)
             N = w.shape[0]
             assert w.shape[1] == K and K % 16 == 0
+            if x_hi is None and res is None and rows <= 64 and K % 64 == 0 and K <= 1024 and x is not None and out is not None:
+                # per-sample layers (time-embedding MLP, FiLM): a few MFLOP in fp32 -- one wave per output column
+                bptr = P(W(lin_b)) if lin_b is not None else None
+                launch(lib.ctdd_hollow_small_linear, P(x), P(w), bptr, rows, K, N, act, P(out), label=f"linear {label} {rows}x{K}->{N} rows",
+                       flops=2 * rows * K * N)
+                return
             a = _ConvArgs()
             a.nseg = 1
             a.seg[0].C, a.seg[0].kind = K, SEG_1x1
@@ -140,7 +151,11 @@ class HollowEngine:
             if split and use_bf16 and (N % 8 != 0 or x_lo is None):
                 assert x is not None, label                      # (a 3-column logits layer: the exact-fp32 kernel)
                 use_bf16 = False
-            if use_bf16 and split:
+            if use_bf16 and split and label in self.single:
+                wh = w.to(torch.bfloat16).contiguous()
+                keep.append(wh)
+                a.seg[0].hi, a.w_hi = P(x_hi), P(wh)
+            elif use_bf16 and split:
                 wh = w.to(torch.bfloat16)
                 wl = (w - wh.float()).to(torch.bfloat16)
                 wcat = torch.cat([wh, wh, wl], dim=1).contiguous()        # [N][3K] against the segments [x_hi | x_lo | x_hi]

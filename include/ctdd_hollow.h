@@ -31,6 +31,9 @@ typedef struct {
 } ctdd_hollow_ln_args;
 int ctdd_hollow_layernorm(const void* ln_args, void* stream);
 
+/* per-sample linears (time-embedding MLP 1136-1156 / 90-132, FiLM layers): out[b][n] = act(bias[n] + sum_k x[b][k] w[n][k]), fp32,
+ * w (N, K) as the module stores it; act 0 none, 1 ReLU, 2 GELU (erf).  K % 64 == 0, K <= 1024. */
+int ctdd_hollow_small_linear(const float* x, const float* w, const float* bias, int B, int K, int N, int act, float* out, void* stream);
 int ctdd_hollow_add(const float* p, int64_t p_bs, const float* q, int64_t q_bs, float* out, void* out_bf16, void* out_lo, int64_t out_bs,
                     int B, int64_t per_batch, void* stream);                            /* l2r + r2l (fp32 and/or bf16 hi (+ lo) result) */
 int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, void* dst_lo, int64_t dst_bs, int B, int E,
