@@ -56,8 +56,10 @@ __device__ inline float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF000
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __host__ __device__ constexpr int slot_of(int c) { return (c + 4) % NSLOT; }
-// DMA ops (4 per chunk per wave) that may stay in flight when chunk c's group 5 waits for chunk c+1
-__host__ __device__ constexpr int mid_wait(int c) { return c == 0 ? 12 : c <= 4 ? 8 : c == 5 ? 4 : 0; }
+// vector-memory operations that may stay in flight when chunk c's group 5 waits for chunk c+1: the DMA pieces of the younger
+// chunks (4 per chunk per wave) and, in chunk 6, the twelve forward-rate loads of the epilogue's first group, requested at
+// group 48 (they are younger than chunk 7's pieces; waiting for them there stalled the last two chunks on an L2 round trip)
+__host__ __device__ constexpr int mid_wait(int c) { return c == 0 ? 12 : c <= 4 ? 8 : c == 5 ? 4 : 12; }
 
 #ifdef CTDD_S256_STAMPS      // diagnostic build only: per-wave phase time stamps go to a.out_changed
 #define B16_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[i] = t_; }
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                        (void __attribute__((address_space(3)))*)(stg + i * 1024), 16, 0, 0);
     }
+    asm volatile("" ::: "memory");                                   // (the gathers below stay behind the DMA issues: counted wait)
     xcur = min(max(xcur, 0), S256 - 1);
     xj = min(max(xj, 0), S256 - 1);
     u32x4 iqb[2][8];
@@ -136,8 +139,11 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) iqb[p][i] = *(const u32x4*)(qrow + 16 * i);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // rows, gathers (and chunk 0) have landed
+    // the rows do not hang on x: wait for them alone (the 16 gathers are the youngest operations), take max / exp / sum while
+    // the gathers -- a second memory latency behind the states' -- are still in flight, multiply when they are there
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     B16_STAMP(5)
+    float ev[2][64];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       u32x4 raw[8];
@@ -158,23 +164,29 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       const float ms = mx * LOG2E;
       float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const u32x4 qb = iqb[p][i];
-        u32x4 w;
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const float e0 = __builtin_amdgcn_exp2f(fmaf(bf_lo(raw[i][d]), LOG2E, -ms));
           const float e1 = __builtin_amdgcn_exp2f(fmaf(bf_hi(raw[i][d]), LOG2E, -ms));
           z0 += e0; z1 += e1;
-          w[d] = pack_bf16(e0 * bf_lo(qb[d]), e1 * bf_hi(qb[d]));
+          ev[p][8 * i + 2 * d] = e0; ev[p][8 * i + 2 * d + 1] = e1;
         }
-        bw[8 * p + i] = w;
-      }
       float z = z0 + z1;
       z += __shfl_xor(z, 16, WAVE);
       z += __shfl_xor(z, 32, WAVE);
       zv = ((q4 & 1) == p) ? z : zv;                                  // the lane that ends up with row 16 p + j16
     }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u32x4 qb = iqb[p][i];
+        u32x4 w;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w[d] = pack_bf16(ev[p][8 * i + 2 * d] * bf_lo(qb[d]), ev[p][8 * i + 2 * d + 1] * bf_hi(qb[d]));
+        bw[8 * p + i] = w;
+      }
   } else {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       if constexpr (c >= 1 && c + 4 < NCHUNK) stage_chunk(c + 4, slot_of(c - 1));
     }
     if constexpr (G + 3 < 64) read_group(std::integral_constant<int, G + 3>{});
-    if constexpr (G == 56) { B16_LOAD_F(fA, 0, 3) }
+    if constexpr (G == 48) { B16_LOAD_F(fA, 0, 3) }      // (the B fragments of K-steps 0..11 are out of use: 48 registers)
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8 b = __builtin_bit_cast(bf16x8, bw[kk]);
     acc[2 * i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[buf][0], b, acc[2 * i], 0, 0, 0);

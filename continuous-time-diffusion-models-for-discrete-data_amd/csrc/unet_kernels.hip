@@ -1701,17 +1701,27 @@ __global__ __launch_bounds__(256) void k_rows_linear(const float* __restrict__ x
   }
 }
 
-// Every sample at the SAME time (all the samplers: t * ones((N,)), sampling.py:119-121): the whole time path -- sinusoid ->
-// W1 -> swish -> W2 -> swish -> this workgroup's 64 columns of all the ResBlock projections -- in ONE launch for one row.
-// Each workgroup recomputes the two hidden layers (74 k multiply-adds) instead of waiting on two more launches: the three
-// row-blocked launches above are latency chains of ~80 us at the head of every forward, this is one of ~10.
-__global__ __launch_bounds__(256) void k_time_uniform(const TimeArgs a, const float* __restrict__ proj_w, const float* __restrict__ proj_b,
-                                                      int Ntot, float* __restrict__ proj_out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // e[ch] | hid[tdim] | act[tdim] | part[4][64]
+// Every sample at the SAME time (all the samplers: t * ones((N,)), sampling.py:119-121): the time path for ONE row, two
+// launches.  k_time_uniform_act: workgroup g computes columns 64 g .. 64 g + 63 of act = swish(W2 swish(W1 e + b1) + b2); each
+// recomputes the first hidden layer (ch x tdim weights, 147 KB at MNIST size) rather than wait on a third launch.
+// k_time_uniform_proj: workgroup g computes 64 columns of all the ResBlock projections.  In both, the four waves split the
+// contraction index and meet in LDS, the loads of a wave's quarter are independent (unrolled 8 deep: the row-blocked
+// three-launch path above is a chain of L2 latencies, ~80 us at the head of every forward; this is ~10).
+__device__ inline float time_quarter_dot(const float* __restrict__ w, const float* __restrict__ src, int K, int N, int n, int ks) {
+  const int kq = K / 4, k0 = ks * kq;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll 2
+  for (int i = k0; i < k0 + kq; i += 4) {
+    s0 = fmaf(w[(size_t)i * N + n], src[i], s0); s1 = fmaf(w[(size_t)(i + 1) * N + n], src[i + 1], s1);
+    s2 = fmaf(w[(size_t)(i + 2) * N + n], src[i + 2], s2); s3 = fmaf(w[(size_t)(i + 3) * N + n], src[i + 3], s3);
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void k_time_uniform_act(const TimeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // e[ch] | hid[tdim] | part[4][64]
   float* e = sm;
   float* hid = e + a.ch;
-  float* act = hid + a.tdim;
-  float* part = act + a.tdim;
+  float* part = hid + a.tdim;
   const float t = a.t[0];
   const int half = a.ch / 2;
   for (int c = threadIdx.x; c < a.ch; c += 256) {
@@ -1720,37 +1730,34 @@ __global__ __launch_bounds__(256) void k_time_uniform(const TimeArgs a, const fl
     e[c] = c < half ? sinf(t * f) : cosf(t * f);
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < a.tdim; n += 256) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (int i = 0; i < a.ch; i += 4) {
-      s0 = fmaf(a.w1[(size_t)i * a.tdim + n], e[i], s0); s1 = fmaf(a.w1[(size_t)(i + 1) * a.tdim + n], e[i + 1], s1);
-      s2 = fmaf(a.w1[(size_t)(i + 2) * a.tdim + n], e[i + 2], s2); s3 = fmaf(a.w1[(size_t)(i + 3) * a.tdim + n], e[i + 3], s3);
+  const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  for (int g0 = 0; g0 < a.tdim; g0 += 64) {                    // first hidden layer, all columns (ch / 4 loads per thread and group)
+    part[ks * 64 + col] = time_quarter_dot(a.w1, e, a.ch, a.tdim, g0 + col, ks);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const float v = ((a.b1[g0 + col] + part[col]) + part[64 + col]) + (part[128 + col] + part[192 + col]);
+      hid[g0 + col] = v / (1.0f + expf(-v));
     }
-    const float v = a.b1[n] + ((s0 + s1) + (s2 + s3));
-    hid[n] = v / (1.0f + expf(-v));
+    __syncthreads();
   }
+  const int n = blockIdx.x * 64 + col;
+  part[ks * 64 + col] = time_quarter_dot(a.w2, hid, a.tdim, a.tdim, n, ks);
   __syncthreads();
-  for (int n = threadIdx.x; n < a.tdim; n += 256) {
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma unroll 4
-    for (int i = 0; i < a.tdim; i += 4) {
-      s0 = fmaf(a.w2[(size_t)i * a.tdim + n], hid[i], s0); s1 = fmaf(a.w2[(size_t)(i + 1) * a.tdim + n], hid[i + 1], s1);
-      s2 = fmaf(a.w2[(size_t)(i + 2) * a.tdim + n], hid[i + 2], s2); s3 = fmaf(a.w2[(size_t)(i + 3) * a.tdim + n], hid[i + 3], s3);
-    }
-    const float v = a.b2[n] + ((s0 + s1) + (s2 + s3));
-    act[n] = v / (1.0f + expf(-v));
+  if (threadIdx.x < 64) {
+    const float v = ((a.b2[n] + part[col]) + part[64 + col]) + (part[128 + col] + part[192 + col]);
+    a.act[n] = v / (1.0f + expf(-v));
   }
+}
+__global__ __launch_bounds__(256) void k_time_uniform_proj(const float* __restrict__ act, int tdim, const float* __restrict__ proj_w,
+                                                           const float* __restrict__ proj_b, int Ntot, float* __restrict__ proj_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // act[tdim] | part[4][64]
+  float* av = sm;
+  float* part = av + tdim;
+  for (int i = threadIdx.x; i < tdim; i += 256) av[i] = act[i];
   __syncthreads();
   const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + col, nc = n < Ntot ? n : Ntot - 1;
-  const int kq = a.tdim / 4, k0 = ks * kq;
-  float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll 4
-  for (int i = k0; i < k0 + kq; i += 2) {
-    s0 = fmaf(proj_w[(size_t)i * Ntot + nc], act[i], s0);
-    s1 = fmaf(proj_w[(size_t)(i + 1) * Ntot + nc], act[i + 1], s1);
-  }
-  part[ks * 64 + col] = s0 + s1;
+  part[ks * 64 + col] = time_quarter_dot(proj_w, av, tdim, Ntot, nc, ks);
   __syncthreads();
   if (threadIdx.x < 64 && n < Ntot)
     proj_out[n] = ((proj_b[n] + part[col]) + part[64 + col]) + (part[128 + col] + part[192 + col]);
@@ -2101,10 +2108,13 @@ extern "C" int ctdd_unet_time(const void* args_, const float* proj_w, const floa
 extern "C" int ctdd_unet_time_uniform(const void* args_, const float* proj_w, const float* proj_b, int Ntot, float* proj_out,
                                       void* stream) {
   const TimeArgs& a = *(const TimeArgs*)args_;
-  CTDD_REQUIRE(a.t && a.tdim % 16 == 0 && a.ch % 16 == 0 && Ntot > 0, CTDD_EINVAL, "bad time arguments");
-  const size_t lds = (size_t)(a.ch + 2 * a.tdim + 256) * sizeof(float);
-  hipLaunchKernelGGL(k_time_uniform, dim3((Ntot + 63) / 64), dim3(256), lds, (hipStream_t)stream, a, proj_w, proj_b, Ntot, proj_out);
-  return finish_launch("k_time_uniform");
+  CTDD_REQUIRE(a.t && a.act && a.tdim % 64 == 0 && a.ch % 16 == 0 && Ntot > 0, CTDD_EINVAL, "bad time arguments (tdim %% 64, ch %% 16)");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_time_uniform_act, dim3(a.tdim / 64), dim3(256), (size_t)(a.ch + a.tdim + 256) * sizeof(float), st, a);
+  if (int rc = finish_launch("k_time_uniform_act")) return rc;
+  hipLaunchKernelGGL(k_time_uniform_proj, dim3((Ntot + 63) / 64), dim3(256), (size_t)(a.tdim + 256) * sizeof(float), st,
+                     (const float*)a.act, a.tdim, proj_w, proj_b, Ntot, proj_out);
+  return finish_launch("k_time_uniform_proj");
 }
 
 extern "C" int ctdd_unet_attention(const void* args_, void* stream) {
