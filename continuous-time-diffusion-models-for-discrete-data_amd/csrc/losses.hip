@@ -172,9 +172,11 @@ extern "C" int ctdd_crm_loss_ll(const float* ll_all, const int32_t* xt, const fl
 //   Wt[s]     = [s != x] R[s,x] q[x0,s] / (q[x0,x] + eps)
 //   outer_row = sum_s Wt[s] inner[s]
 //   norm_row  = sum_s [s != x] R[s,x] q[x0,s] / (Z[s] (q[x0,x] + eps)),  Z[s] = sum_d' rs[x~_bd'] - rs[x] + rs[s], rs = -diag R
-//   loss = elbo_scale * ( mean_b( -sum_d outer / sum_d norm ) + mean_b sum_d reg ) + nll_scale * sum_{b,d} -log p[x0]
+//   loss = elbo_scale * mean_b( -sum_d outer / sum_d norm ) + reg_scale * mean_b sum_d reg + nll_scale * sum_{b,d} -log p[x0]
+//   (reg_scale = elbo_scale for the one-forward-pass objective; ctdd_ctelbo_loss_terms exposes the two weights so that the
+//    two-forward-pass objective is two launches, one per network output)
 // Backward: G[s] = c_b Wt[s] / (u[s] + eps), c_b = -elbo_scale / (B norm_b);  dr[s0] = sum_s G[s] q[s0,s];
-//   dp[s0] = dr[s0] / (q[s0,x] + eps) + (elbo_scale / B) A[x][s0];  dl[j] = p[j] (dp[j] - sum p dp) + nll_scale (p[j] - [j = x0]).
+//   dp[s0] = dr[s0] / (q[s0,x] + eps) + (reg_scale / B) A[x][s0];  dl[j] = p[j] (dp[j] - sum p dp) + nll_scale (p[j] - [j = x0]).
 // Workgroup = 8 rows of one sample, thread s <-> state s (S <= 256); the two S x S contractions stream q / qT
 // once per 8 rows with the row vectors in LDS.  Correctness-first (fp32 FMA chains, no matrix cores yet).
 namespace ctdd {
@@ -185,6 +187,8 @@ struct ElboArgs {
   const float* logits; const int32_t* x0; const int32_t* xt;     // xt = x~ (= reg_x)
   const float* q; const float* qT; const float* R;               // (B,S,S) each
   int B, D, S; float eps, elbo_scale, nll_scale;
+  float reg_scale;    // weight of the regulariser term (= elbo_scale in the one-forward-pass objective; the two-pass objective runs
+                      // the kernel once per network output with one of the two term weights at zero)
   float* Atab;        // (B,S,S): A[b][x][s0]
   float* base_sum;    // (B)
   float* u;           // (B,D,S)
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256) void k_elbo_reduce(const ElboArgs a, const dou
   for (int b = threadIdx.x; b < a.B; b += 256) {
     const double so = sums[(size_t)b * 4], sn = sums[(size_t)b * 4 + 1], sr = sums[(size_t)b * 4 + 2], sl = sums[(size_t)b * 4 + 3];
     a.cb[b] = (float)(-(double)a.elbo_scale / ((double)a.B * sn));
-    tot += (double)a.elbo_scale * ((-so / sn) + sr) / (double)a.B + (double)a.nll_scale * sl;
+    tot += ((double)a.elbo_scale * (-so / sn) + (double)a.reg_scale * sr) / (double)a.B + (double)a.nll_scale * sl;
   }
   acc[threadIdx.x] = tot;
   __syncthreads();
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
 #pragma unroll
   for (int r = 0; r < LRB; ++r) {
     dp[r] = 0.0f;
-    if (act) dp[r] = acc[r] / (qT[(size_t)x[r] * S + t] + a.eps) + (a.elbo_scale / (float)a.B) * a.Atab[((size_t)b * S + x[r]) * S + t];
+    if (act) dp[r] = acc[r] / (qT[(size_t)x[r] * S + t] + a.eps) + (a.reg_scale / (float)a.B) * a.Atab[((size_t)b * S + x[r]) * S + t];
     pd[r] = p[r] * dp[r];
   }
   float pdot[LRB];
@@ -554,16 +558,26 @@ extern "C" int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S) {
   return al((int64_t)B * S * S * 4) + al((int64_t)B * D * S * 4) + al((int64_t)B * D * 32) + 2 * al((int64_t)B * 4) + al((int64_t)B * 32);
 }
 
+extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
+                                      const float* rate, int B, int D, int S, float eps, float sig_scale, float reg_scale, float nll_scale,
+                                      void* scratch, float* grad_logits, float* out_loss, void* stream);
 extern "C" int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
                                 const float* rate, int B, int D, int S, float eps, float elbo_scale, float nll_scale,
                                 void* scratch, float* grad_logits, float* out_loss, void* stream) {
+  return ctdd_ctelbo_loss_terms(logits, x0, x_tilde, qt0, qt0T, rate, B, D, S, eps, elbo_scale, elbo_scale, nll_scale, scratch, grad_logits,
+                                out_loss, stream);
+}
+extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
+                                      const float* rate, int B, int D, int S, float eps, float sig_scale, float reg_scale, float nll_scale,
+                                      void* scratch, float* grad_logits, float* out_loss, void* stream) {
+  const float elbo_scale = sig_scale;
   CTDD_REQUIRE(logits && x0 && x_tilde && qt0 && qt0T && rate && scratch && grad_logits && out_loss, CTDD_EINVAL, "ct-elbo: null buffer");
   CTDD_REQUIRE(B > 0 && D > 0 && S >= 2 && S <= 256, CTDD_ERANGE, "ct-elbo: B=%d D=%d S=%d (S <= 256)", B, D, S);
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
   unsigned char* sp = (unsigned char*)scratch;
   ElboArgs a;
   a.logits = logits; a.x0 = x0; a.xt = x_tilde; a.q = qt0; a.qT = qt0T; a.R = rate;
-  a.B = B; a.D = D; a.S = S; a.eps = eps; a.elbo_scale = elbo_scale; a.nll_scale = nll_scale;
+  a.B = B; a.D = D; a.S = S; a.eps = eps; a.elbo_scale = elbo_scale; a.nll_scale = nll_scale; a.reg_scale = reg_scale;
   a.Atab = (float*)sp; sp += al((int64_t)B * S * S * 4);
   a.u = (float*)sp; sp += al((int64_t)B * D * S * 4);
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
@@ -728,7 +742,7 @@ static int score_elbo_impl(const float* logits, const int32_t* x0, const int32_t
   unsigned char* sp = (unsigned char*)scratch;          // same layout as ctdd_ctelbo_scratch_bytes
   ElboArgs a;
   a.logits = logits; a.x0 = x0; a.xt = x_tilde; a.q = qt0; a.qT = qt0; a.R = rate;
-  a.B = B; a.D = D; a.S = S; a.eps = eps; a.elbo_scale = 1.0f; a.nll_scale = nll_scale;
+  a.B = B; a.D = D; a.S = S; a.eps = eps; a.elbo_scale = 1.0f; a.nll_scale = nll_scale; a.reg_scale = 1.0f;
   a.Atab = (float*)sp; sp += al((int64_t)B * S * S * 4);
   a.u = (float*)sp; sp += al((int64_t)B * D * S * 4);
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);

@@ -56,6 +56,7 @@ _SIGS = {
     "ctdd_crm_loss": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_ctelbo_scratch_bytes": ([_I, _I, _I], _I64),
     "ctdd_ctelbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P], _I),
+    "ctdd_ctelbo_loss_terms": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_score_elbo_loss": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
     "ctdd_crm_loss_ll": ([_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P], _I),
     "ctdd_score_elbo_loss_ll": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P], _I),
@@ -402,17 +403,23 @@ def score_elbo_loss(logits, x0, x_tilde, reg_x, qt0, rate, eps, nll_scale):
     return out[0], grad
 
 
-def ctelbo_loss(logits, x0, x_tilde, qt0, qt0T, rate, eps, elbo_scale, nll_scale):
-    """K11: (loss scalar tensor, d loss / d logits) of the tauLDR CT-ELBO (one forward pass)."""
+def ctelbo_loss(logits, x0, x_tilde, qt0, qt0T, rate, eps, elbo_scale, nll_scale, reg_scale=None):
+    """K11: (loss scalar tensor, d loss / d logits) of the tauLDR CT-ELBO.  `reg_scale` None: the one-forward-pass objective
+    (both ELBO terms weighted `elbo_scale`); otherwise the signal term is weighted `elbo_scale` and the regulariser
+    `reg_scale`, every term evaluated at the state passed as `x_tilde` (one half of the two-forward-pass objective)."""
     B, D, S = logits.shape
     lib = load()
     scratch = torch.empty((int(lib.ctdd_ctelbo_scratch_bytes(B, D, S)),), dtype=torch.uint8, device=logits.device)
     grad = torch.empty_like(logits)
     out = torch.empty((1,), dtype=torch.float32, device=logits.device)
-    _check(lib.ctdd_ctelbo_loss(_ptr(logits, torch.float32, "logits"), _ptr(x0, torch.int32, "x0"), _ptr(x_tilde, torch.int32, "x_tilde"),
-                                _ptr(qt0, torch.float32, "qt0"), _ptr(qt0T, torch.float32, "qt0T"), _ptr(rate, torch.float32, "rate"),
-                                B, D, S, float(eps), float(elbo_scale), float(nll_scale), _ptr(scratch), _ptr(grad), _ptr(out),
-                                _stream()), "ctdd_ctelbo_loss")
+    head = (_ptr(logits, torch.float32, "logits"), _ptr(x0, torch.int32, "x0"), _ptr(x_tilde, torch.int32, "x_tilde"),
+            _ptr(qt0, torch.float32, "qt0"), _ptr(qt0T, torch.float32, "qt0T"), _ptr(rate, torch.float32, "rate"), B, D, S, float(eps))
+    tail = (float(nll_scale), _ptr(scratch), _ptr(grad), _ptr(out), _stream())
+    _count("ctdd_ctelbo_loss" if reg_scale is None else "ctdd_ctelbo_loss_terms")
+    if reg_scale is None:
+        _check(lib.ctdd_ctelbo_loss(*head, float(elbo_scale), *tail), "ctdd_ctelbo_loss")
+    else:
+        _check(lib.ctdd_ctelbo_loss_terms(*head, float(elbo_scale), float(reg_scale), *tail), "ctdd_ctelbo_loss_terms")
     return out[0], grad
 
 

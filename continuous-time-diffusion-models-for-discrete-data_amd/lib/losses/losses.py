@@ -70,17 +70,17 @@ class _CtElboFn(torch.autograd.Function):
     """K11 (csrc/losses.hip): CT-ELBO value and logit-gradient in HIP (one forward pass)."""
 
     @staticmethod
-    def forward(ctx, logits, x0, x_tilde, qt0, qt0T, rate, eps, elbo_scale, nll_scale):
+    def forward(ctx, logits, x0, x_tilde, qt0, qt0T, rate, eps, elbo_scale, nll_scale, reg_scale=None):
         val, grad = native.ctelbo_loss(logits.detach().float().contiguous(), x0.to(torch.int32).contiguous(),
                                        x_tilde.to(torch.int32).contiguous(), qt0.contiguous(), qt0T.contiguous(),
-                                       rate.contiguous(), eps, elbo_scale, nll_scale)
+                                       rate.contiguous(), eps, elbo_scale, nll_scale, reg_scale)
         ctx.save_for_backward(grad)
         return val
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return (grad * g,) + (None,) * 8
+        return (grad * g,) + (None,) * 9
 
 
 def _masked_rows(tab, x):
@@ -121,17 +121,26 @@ class _CTElboBase:
         self.cross_ent = nn.CrossEntropyLoss()
 
     def _total(self, state, minibatch, elbo_scale, nll_coef):
-        """elbo_scale * neg_elbo + nll_coef * CE(logits, x0).  With one forward pass on a GPU the objective and
-        its logit gradient run in K11 (csrc/losses.hip); two forward passes keep the differentiable device ops."""
+        """elbo_scale * neg_elbo + nll_coef * CE(logits, x0).  On a GPU the objective and its logit gradient run in K11
+        (csrc/losses.hip): one launch chain with one forward pass, one per network output with two."""
         model = state["model"]
         x0 = _flatten(minibatch).long()
         B, D = x0.shape
         ts = _draw_ts(B, model.device, self.min_time, self.max_t)
         qt0, rate, x_t, x_tilde, qT = _noise(model, x0, ts, True, want_T=True)
         x_logits = model(x_t, ts)
-        if self.one_forward_pass and x_logits.is_cuda and x_logits.shape[-1] <= 256 and getattr(self.cfg.loss, "fused", True):
+        fused = x_logits.is_cuda and x_logits.shape[-1] <= 256 and getattr(self.cfg.loss, "fused", True)
+        if self.one_forward_pass and fused:
             return _CtElboFn.apply(x_logits, x0, x_tilde, qt0, qT, rate, float(self.ratio_eps), float(elbo_scale),
                                    float(nll_coef) / (B * D))
+        if fused:
+            # two forward passes (losses.py:150-158): the regulariser and the cross entropy see model(x_t) at reg_x = x_t,
+            # the signal term sees model(x~) at x~  --  K11 once per network output with the other term's weight at zero
+            logits_sig = model(x_tilde, ts)
+            eps, w = float(self.ratio_eps), float(elbo_scale)
+            reg = _CtElboFn.apply(x_logits, x0, x_t, qt0, qT, rate, eps, 0.0, float(nll_coef) / (B * D), w)
+            sig = _CtElboFn.apply(logits_sig, x0, x_tilde, qt0, qT, rate, eps, w, 0.0, 0.0)
+            return reg + sig
         if self.one_forward_pass:
             logits_sig, reg_x = x_logits, x_tilde
         else:

@@ -212,6 +212,14 @@ int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S);
 int ctdd_ctelbo_loss(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
                      const float* rate, int B, int D, int S, float eps, float elbo_scale, float nll_scale,
                      void* scratch, float* grad_logits, float* out_loss, void* stream);
+/* The same kernels with the two ELBO terms weighted separately -- the building block of one_forward_pass = False
+ * (lib/losses/losses.py:150-158: p0t_reg = softmax(model(x_t)) with reg_x = x_t, p0t_sig = softmax(model(x~))):
+ *   out_loss = sig_scale * mean_b(-sig_b / norm_b) + reg_scale * mean_b(reg_b) + nll_scale * sum_{b,d} -log_softmax(logits)[x0]
+ * with every term evaluated at the state passed as x_tilde.  The two-pass objective is
+ *   terms(model(x_t), x_tilde := x_t, sig 0, reg w, nll) + terms(model(x~), x_tilde := x~, sig w, reg 0, nll 0). */
+int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
+                           const float* rate, int B, int D, int S, float eps, float sig_scale, float reg_scale, float nll_scale,
+                           void* scratch, float* grad_logits, float* out_loss, void* stream);
 
 /* ---- ScoreElbo with direct logits (lib/losses/losses.py:1255-1500), value and d/dlogits:
  * out_loss = mean_b(-sig_b / norm_b) + mean_b(reg_b) + nll_scale * sum_{b,d} -log_softmax(logits)[x~]   (nll_scale = nll_weight / B).
