@@ -48,7 +48,9 @@ struct PhiloxStream {
       blk = philox_row(seed, offset, row, draw++);
       used = 0;
     }
-    const uint32_t r = used == 0 ? blk.x : used == 1 ? blk.y : used == 2 ? blk.z : blk.w;
+    // (bit selects: the chain of equality tests became four branches in the callers' loops)
+    const uint32_t r01 = (used & 1) ? blk.y : blk.x, r23 = (used & 1) ? blk.w : blk.z;
+    const uint32_t r = (used & 2) ? r23 : r01;
     ++used;
     return u01(r);
   }

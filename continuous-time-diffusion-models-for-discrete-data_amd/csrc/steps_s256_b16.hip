@@ -53,6 +53,35 @@ __device__ inline unsigned pack_bf16(float a, float b) {       // -> v_cvt_pk_bf
 __device__ inline float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ inline float bf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
+// The two lanes of a pair (l, l ^ 32) both get (value of the lower lane, value of the upper lane): one v_permlane32_swap on the
+// vector ALU instead of a ds_bpermute round trip through the LDS queue.
+__device__ inline void pair_values(unsigned mine, unsigned& lower, unsigned& upper) {
+  const auto r = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+  lower = r[0]; upper = r[1];
+}
+__device__ inline float pair_sum(float v) {                     // lower + upper, bitwise the same in both lanes
+  unsigned lo, hi;
+  pair_values(__float_as_uint(v), lo, hi);
+  return __uint_as_float(lo) + __uint_as_float(hi);
+}
+__device__ inline int pair_sum(int v) {
+  unsigned lo, hi;
+  pair_values((unsigned)v, lo, hi);
+  return (int)(lo + hi);
+}
+__device__ inline float quad_max(float v) {                     // over the four lanes l ^ {0, 16, 32, 48}
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  unsigned lo, hi;
+  pair_values(__float_as_uint(v), lo, hi);
+  return fmaxf(__uint_as_float(lo), __uint_as_float(hi));
+}
+__device__ inline float quad_sum(float v) {                     // (v[l] + v[l ^ 16]) + (the same of the other half), as the shuffles summed
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  return pair_sum(v);
+}
+
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __host__ __device__ constexpr int slot_of(int c) { return (c + 4) % NSLOT; }
@@ -159,8 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) { m0 = fmaxf(m0, bf_lo(raw[i][d])); m1 = fmaxf(m1, bf_hi(raw[i][d])); }
       float mx = fmaxf(m0, m1);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+      mx = quad_max(mx);
       const float ms = mx * LOG2E;
       float z0 = 0.0f, z1 = 0.0f;
 #pragma unroll
@@ -173,8 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
           ev[p][8 * i + 2 * d] = e0; ev[p][8 * i + 2 * d + 1] = e1;
         }
       float z = z0 + z1;
-      z += __shfl_xor(z, 16, WAVE);
-      z += __shfl_xor(z, 32, WAVE);
+      z = quad_sum(z);
       zv = ((q4 & 1) == p) ? z : zv;                                  // the lane that ends up with row 16 p + j16
     }
 #pragma unroll
@@ -242,8 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       m0 = fmaxf(m0, raw[k].x); m1 = fmaxf(m1, raw[k].y); m2 = fmaxf(m2, raw[k].z); m3 = fmaxf(m3, raw[k].w);
     }
     float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+    mx = quad_max(mx);
     const float ms = mx * LOG2E;
     float z0 = 0.0f, z1 = 0.0f, z2 = 0.0f, z3 = 0.0f;
 #pragma unroll
@@ -255,8 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       z0 += raw[k].x; z1 += raw[k].y; z2 += raw[k].z; z3 += raw[k].w;
     }
     float z = (z0 + z1) + (z2 + z3);
-    z += __shfl_xor(z, 16, WAVE);
-    z += __shfl_xor(z, 32, WAVE);
+    z = quad_sum(z);
     zv = ((q4 & 1) == p) ? z : zv;                                  // the lane that ends up with row 16 p + j16
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -354,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
     for (int m = 0; m < 8; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ox = (32 * m + 8 * (r >> 2) + 4 * g + (r & 3) == xj) ? acc[m][r] : ox;
-    ox += __shfl_xor(ox, 32, WAVE);
+    ox = pair_sum(ox);
     addn = 1e-35f * zv;
     norm = ox + addn;
   }
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
   apply(std::integral_constant<int, 7>{}, fA[1]);
 #undef B16_LOAD_F
   float T = (T0 + T1) + (T2 + T3);
-  T += __shfl_xor(T, 32, WAVE);
+  T = pair_sum(T);
   if (GENERAL && a.out_rates && !a.out_x) return;
   B16_STAMP(3)
 
@@ -445,10 +470,9 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
         const int mm = m & 3;
         // each lane builds Philox block 2m+g and trades it with its partner, so both see blocks 2m and 2m+1
         const u4 mine = philox_row(a.seed, a.offset, rngrow, DENSE_DRAW0 + (uint32_t)(2 * m + g));
-        u4 oth;
-        oth.x = __shfl_xor(mine.x, 32, WAVE); oth.y = __shfl_xor(mine.y, 32, WAVE);
-        oth.z = __shfl_xor(mine.z, 32, WAVE); oth.w = __shfl_xor(mine.w, 32, WAVE);
-        const u4 lo = g == 0 ? mine : oth, hi = g == 0 ? oth : mine;      // blocks 2m, 2m+1
+        u4 lo, hi;                                                         // blocks 2m, 2m+1
+        pair_values(mine.x, lo.x, hi.x); pair_values(mine.y, lo.y, hi.y);
+        pair_values(mine.z, lo.z, hi.z); pair_values(mine.w, lo.w, hi.w);
         const uint32_t w0 = g == 0 ? lo.x : lo.y, w1 = g == 0 ? lo.z : lo.w;
         const uint32_t w2 = g == 0 ? hi.x : hi.y, w3 = g == 0 ? hi.z : hi.w;
         const float4 v0 = rl4[(4 * mm + 0) * 64], v1 = rl4[(4 * mm + 1) * 64], v2 = rl4[(4 * mm + 2) * 64],
@@ -462,8 +486,13 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       asm volatile("" ::: "memory");
     }
     if (dense) {
-      cnt += __shfl_xor(cnt, 32, WAVE);
-      jl += __shfl_xor(jl, 32, WAVE);
+      cnt = pair_sum(cnt);
+      {
+        unsigned l0, h0, l1, h1;
+        pair_values((unsigned)(unsigned long long)jl, l0, h0);
+        pair_values((unsigned)((unsigned long long)jl >> 32), l1, h1);
+        jl = (long long)(((unsigned long long)l1 << 32) | l0) + (long long)(((unsigned long long)h1 << 32) | h0);
+      }
       jl = jl > S256 ? S256 : (jl < -S256 ? -S256 : jl);        // |jump| >= S - 1 saturates the state clamp either way
       jump = (ordinal || cnt <= 1) ? (int)jl : 0;
       njumps = cnt;
@@ -494,15 +523,17 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
         const int m = i >> 1, q = 2 * (i & 1) + bb;
         const float v0 = acc[m][4 * q], v1 = acc[m][4 * q + 1], v2 = acc[m][4 * q + 2], v3 = acc[m][4 * q + 3];
         const float mine = (v0 + v1) + (v2 + v3);
-        const float other = __shfl_xor(mine, 32, WAVE);
-        float c = run + (g == 0 ? 0.0f : other);
+        unsigned lo_, hi_;
+        pair_values(__float_as_uint(mine), lo_, hi_);
+        const float first = __uint_as_float(lo_), second = __uint_as_float(hi_);   // the block's g = 0 / g = 1 four
+        float c = run + (g == 0 ? 0.0f : first);
         if (bb == 0) gstart = c;
         c += v0; rel[4 * bb + 0] = c - gstart;
         c += v1; rel[4 * bb + 1] = c - gstart;
         c += v2; rel[4 * bb + 2] = c - gstart;
         c += v3; rel[4 * bb + 3] = c - gstart;
         acc[m][4 * q + 3] = c;                                    // (only the bb = 1 value is read again)
-        run += (g == 0 ? mine + other : other + mine);
+        run += first + second;
       }
       uint4 pk;
       pk.x = pack_bf16(rel[0], rel[1]); pk.y = pack_bf16(rel[2], rel[3]);
@@ -511,20 +542,36 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
       gsv[i * 64] = gstart;
     }
     if (picks) {
+      // A pick is kept to ~45 instructions: no compare-to-mask / mask-to-register pairs (each costs its own wait states) --
+      //  * group ends <= target: the sign bits of (target - end) shifted into one word, counted at the end (all values are
+      //    finite and >= 0, and x - x = +0, so "sign clear" is exactly "end <= target");
+      //  * the 7 bf16 offsets <= dlt: non-negative floats order as their bit patterns and a bf16 pattern has no low half, so
+      //    b <= dlt  <=>  bits16(b) <= bits(dlt) >> 16 as integers: four packed 16-bit subtractions, sign bits counted
+      //    (dlt < 0 -- the target lies in the partner's half of the block -- becomes -1: below every pattern);
+      //  * the partner's count by v_permlane32_swap.
+      using i16x2 = __attribute__((ext_vector_type(2))) short;
       for (int d = 0; d < K; ++d) {
         const float target = rng.next() * T;
-        // destinations with cumulative <= target precede the pick: count mine, add the partner's
-        int nb = 0;
+        unsigned signs = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) nb += (acc[i >> 1][8 * (i & 1) + 7] <= target) ? 1 : 0;
+        for (int i = 0; i < 16; ++i)
+          signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(target - acc[i >> 1][8 * (i & 1) + 7]), 31);
+        const int nb = 16 - __builtin_popcount(signs);           // groups that end at or before the target
         int cnt = 8 * nb;
         if (nb < 16) {
           const uint4 pk = relv[nb * 64];
           const float dlt = target - gsv[nb * 64];
-          cnt += (bf_lo(pk.x) <= dlt) + (bf_hi(pk.x) <= dlt) + (bf_lo(pk.y) <= dlt) + (bf_hi(pk.y) <= dlt) +
-                 (bf_lo(pk.z) <= dlt) + (bf_hi(pk.z) <= dlt) + (bf_lo(pk.w) <= dlt);
+          const int di = max((int)__float_as_uint(dlt), -1) >> 16;
+          const unsigned dd = ((unsigned)di & 0xFFFFu) * 0x10001u;
+          const i16x2 d2 = __builtin_bit_cast(i16x2, dd);
+          const unsigned s0 = __builtin_bit_cast(unsigned, d2 - __builtin_bit_cast(i16x2, pk.x));
+          const unsigned s1 = __builtin_bit_cast(unsigned, d2 - __builtin_bit_cast(i16x2, pk.y));
+          const unsigned s2 = __builtin_bit_cast(unsigned, d2 - __builtin_bit_cast(i16x2, pk.z));
+          const unsigned s3 = __builtin_bit_cast(unsigned, d2 - __builtin_bit_cast(i16x2, pk.w));
+          const unsigned neg = (s0 & 0x80008000u) | ((s1 & 0x80008000u) >> 1) | ((s2 & 0x80008000u) >> 2) | ((s3 & 0x00008000u) >> 3);
+          cnt += 7 - __builtin_popcount(neg);
         }
-        cnt += __shfl_xor(cnt, 32, WAVE);
+        cnt = pair_sum(cnt);
         jump += min(cnt, S256 - 1) - xj;
       }
     }
@@ -538,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void k_tauleap_s256_b16(const S256Args a) {
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     o[6] = rt0_;   (void)xcc; (void)hwid;
-    o[7] = stamps[5];
+    o[7] = ((unsigned long long)xcc << 32) | hwid;
   }
   return;
 #endif

@@ -1222,6 +1222,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
 
 #ifdef CTDD_RES_STAMPS
   unsigned long long tk0, tk1, tk2, tk3, tk4, dur[6] = {0, 0, 0, 0, 0, 0}, tstart;
+  unsigned long long tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0, tl4 = 0, tl5 = 0, tl6 = 0, tl7 = 0;
   RSTAMP(tstart)
 #endif
   // ---- prologue: the first DEPTH units of this z-slice, all ops at once
@@ -1283,6 +1284,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
     RSTAMP(tk3)
 #ifdef CTDD_RES_STAMPS
     dur[0] += tk1 - tk0; dur[1] += tk2 - tk1; dur[3] += tk4 - tk2; dur[4] += tk3 - tk4;
+    {                                       // time line of the first eight units (scalar registers only: nothing in the memory queues)
+      const unsigned long long rel = tk2 - tentry;
+      tl0 = k == 0 ? rel : tl0; tl1 = k == 1 ? rel : tl1; tl2 = k == 2 ? rel : tl2; tl3 = k == 3 ? rel : tl3;
+      tl4 = k == 4 ? rel : tl4; tl5 = k == 5 ? rel : tl5; tl6 = k == 6 ? rel : tl6; tl7 = k == 7 ? tk0 - tentry : tl7;
+    }
 #endif
     if (DEPTH == 2) { cur = nx1; nx1 = nxt; } else { cur = nxt; }
     buf = buf + 1 == NBUF ? 0 : buf + 1;
@@ -1349,6 +1355,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_conv_ring(const Co
     RSTAMP(tdone)
     if (lane == 0 && a.acc_buf) {
       unsigned long long* o = (unsigned long long*)a.acc_buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+      unsigned long long* o2 = o + (size_t)gridDim.x * gridDim.y * NW * 8;     // second table: the unit time line + the raw main-loop sums
+      o2[0] = tl0; o2[1] = tl1; o2[2] = tl2; o2[3] = tl3; o2[4] = tl4; o2[5] = tl5; o2[6] = o[6] - tentry; o2[7] = tep1 - tentry;
+      o2 += (size_t)gridDim.x * gridDim.y * NW * 8;                               // third: dma wait, barrier wait, prologue, unit set-up, taps
+      o2[0] = o[0]; o2[1] = o[1]; o2[2] = o[2]; o2[3] = o[3]; o2[4] = o[4]; o2[5] = tentry; o2[6] = tl6; o2[7] = tl7;
       o[0] = ept[0]; o[1] = ept[1]; o[2] = ept[2];          // epilogue phases 1, 2, 3 (overwrite the dma-wait / barrier / prologue slots)
       o[3] = tep0 - o[6];                                     // tile_stats_begin (barriers + zeroing)
       o[4] = tdone - tep1;                                    // flush

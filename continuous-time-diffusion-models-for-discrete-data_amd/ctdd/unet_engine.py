@@ -288,7 +288,9 @@ class UNetEngine:
                 if a.ksplit > 1:
                     cur_lists["zero"].append((a, M_ * N))
                 fn = lib.ctdd_unet_conv_res if resident else lib.ctdd_unet_conv_ring
-                launch(fn, C.byref(a), bnt, label=lab + f" {which} bnt={bnt} ks={a.ksplit}", flops=2 * M_ * N * Ktot)
+                # (ring_small_tiles: 256-pixel tiles, four waves, two workgroups per CU -- the variant two concurrent chains can share a CU with)
+                sel = bnt + 10 if (ring and bnt in (2, 3) and getattr(m, "ring_small_tiles", 0)) else bnt
+                launch(fn, C.byref(a), sel, label=lab + f" {which} bnt={sel} ks={a.ksplit}", flops=2 * M_ * N * Ktot)
             elif patchable:
                 # throughput kernel: slab staged once per channel chunk (csrc/unet_kernels.hip: k_conv_patch)
                 small = -(-M_ // 128) * -(-N // 96) < 256            # too few 128 x 96 tiles to fill the chip: 32-column tiles

@@ -19,7 +19,7 @@ def run(B, H, W, Cs, N, bnt, kern='ctdd_unet_conv_ring'):
         a.seg[i].hi, a.seg[i].C, a.seg[i].kind = x.data_ptr(), Cs[i], 0
     out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
     nwg = -(-M // 512) * -(-N // (32 * bnt))
-    buf = torch.zeros((nwg * 8 * 8,), dtype=torch.int64, device="cuda")
+    buf = torch.zeros((3 * nwg * 8 * 8,), dtype=torch.int64, device="cuda")      # (the ring kernel writes three tables: tools/stamp_ring_timeline.py)
     stats = torch.zeros((B, N, 2), dtype=torch.float64, device="cuda")
     a.w_hi, a.B, a.H, a.W, a.Hin, a.Win, a.N, a.Ktot = w.data_ptr(), B, H, W, H, W, N, K
     a.out_hi, a.stats, a.ksplit, a.acc_buf = out.data_ptr(), stats.data_ptr(), 1, buf.data_ptr()
@@ -27,7 +27,7 @@ def run(B, H, W, Cs, N, bnt, kern='ctdd_unet_conv_ring'):
     for _ in range(3):
         assert getattr(l, kern)(C.byref(a), bnt, st) == 0, l.ctdd_last_error().decode()
     torch.cuda.synchronize()
-    d = buf.cpu().numpy().reshape(nwg, 8, 8)
+    d = buf.cpu().numpy()[: nwg * 64].reshape(nwg, 8, 8)
     names = ["epi phase1", "epi phase2", "epi phase3", "stats begin", "flush"]
     tot = d[:, :, 7].astype(np.float64)
     print(kern, f"B={B} {H}x{W} C={Cs} N={N}: {nwg} WGs; wave total ticks mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
