@@ -353,9 +353,13 @@ class UNetEngine:
         pb = torch.cat([rb.time[1].bias.detach().float() for rb in resblocks], 0).contiguous()
         Ntot = pw.shape[1]
         st.tact = torch.empty((B, tdim), dtype=torch.float32, device=dev)
+        time_row = uniform_t == "row" and tc is None
         uniform_t = bool(uniform_t) and tc is None
         # uniform_t: every sample at the same time (the samplers): ONE projection row from one fused launch, read by the
-        # convolutions with a zero batch stride (csrc/unet_kernels.hip: k_time_uniform)
+        # convolutions with a zero batch stride (csrc/unet_kernels.hip: k_time_uniform).  "row": that row comes from the caller
+        # (a sampler's grid of times is known when it starts: time_table() computes every step's row at once) -- no time
+        # launch in the plan at all
+        st.time_row = time_row
         st.tproj = torch.empty((1 if uniform_t else B, Ntot), dtype=torch.float32, device=dev)
         tb_stride = 0 if uniform_t else Ntot
         ta = _TimeArgs()
@@ -365,8 +369,10 @@ class UNetEngine:
         ta.t, ta.B, ta.ch, ta.tdim = ptr(st.t_in), B, ch, tdim
         ta.w1, ta.b1, ta.w2, ta.b2, ta.hid, ta.act = ptr(tw[0]), ptr(tw[1]), ptr(tw[2]), ptr(tw[3]), ptr(st.thid), ptr(st.tact)
         keep.extend(tw + [pw, pb, ta])
-        if tc is None:
+        if tc is None and not time_row:
             launch(lib.ctdd_unet_time_uniform if uniform_t else lib.ctdd_unet_time, C.byref(ta), ptr(pw), ptr(pb), Ntot, ptr(st.tproj))
+        elif tc is None:
+            st.tproj.zero_()
         else:
             tc.tproj, tc.resblocks = st.tproj, resblocks          # filled by the caller before the plan runs
         toff = {}
@@ -542,11 +548,11 @@ class UNetEngine:
         for step in st.plan:
             step()
 
-    def _prepare(self, B, x_dtype, x, times, logits_out=None, logits_bf16=False, uniform_t=False):
+    def _prepare(self, B, x_dtype, x, times, logits_out=None, logits_bf16=False, uniform_t=False, time_row=None):
         """Build, warm up and capture the plan for (B, dtype)."""
         st = self._build(B, x_dtype, logits_out, logits_bf16=logits_bf16, uniform_t=uniform_t)
         st.x_in.copy_(x.reshape(st.x_in.shape))
-        st.t_in.copy_(times.float())
+        self._set_time(st, times, time_row)
         self._run_plan(st)                    # eager warm-up (also sets the LDS attributes)
         torch.cuda.synchronize()
         if getattr(self.cfg.model, "engine_graph", True):
@@ -565,9 +571,18 @@ class UNetEngine:
         return st
 
     @staticmethod
-    def _replay(st, x, times):
+    def _set_time(st, times, time_row):
+        if st.time_row:
+            if time_row is None or time_row.numel() != st.tproj.numel():
+                raise native.CtddError("UNetEngine: this plan takes a precomputed time-projection row (time_table()[i])")
+            st.tproj.copy_(time_row.reshape(st.tproj.shape))
+        else:
+            st.t_in.copy_(times.float())
+
+    @staticmethod
+    def _replay(st, x, times, time_row=None):
         st.x_in.copy_(x.reshape(st.x_in.shape))
-        st.t_in.copy_(times.float())
+        UNetEngine._set_time(st, times, time_row)
         if st.graph is not None:
             st.graph.replay()
         else:
@@ -575,7 +590,37 @@ class UNetEngine:
                 pass
             raise native.CtddError("eager replay goes through _run_plan")
 
-    def __call__(self, x, times, logits_bf16=False, uniform_time=False, slot=None):
+    def time_table(self, times):
+        """(T,) times -> (T, Ntot) fp32: the time embedding MLP and every ResBlock's time projection for T time values at once
+        (`ctdd_unet_time`, the per-sample path with the T values as its rows).  A sampler computes it for its whole grid when it
+        starts and hands row i to step i (`time_row=`): the plans then run without the two time launches at their head."""
+        lib = _lib()
+        net, dev = self.net, self.dev
+        ver = self._weights_version()
+        tw_ = self.__dict__.get("_time_w")
+        if tw_ is None or tw_[0] != ver:
+            ch = self.cfg.model.ch
+            resblocks = [mod.resblocks for mod in list(net.down) + list(net.mid) + list(net.up) if hasattr(mod, "resblocks")]
+            pw = torch.cat([rb.time[1].weight.detach().float() for rb in resblocks], 0).t().contiguous()   # [tdim][Ntot]
+            pb = torch.cat([rb.time[1].bias.detach().float() for rb in resblocks], 0).contiguous()
+            tw = [net.time[1].weight.t(), net.time[1].bias, net.time[3].weight.t(), net.time[3].bias]
+            tw = [w.detach().float().contiguous() for w in tw]
+            tw_ = self._time_w = (ver, ch, pw, pb, tw)
+        _, ch, pw, pb, tw = tw_
+        t = times.to(dev).float().contiguous().reshape(-1)
+        T, tdim, Ntot = t.numel(), ch * 4, pw.shape[1]
+        hid = torch.empty((T, tdim), dtype=torch.float32, device=dev)
+        act = torch.empty((T, tdim), dtype=torch.float32, device=dev)
+        out = torch.empty((T, Ntot), dtype=torch.float32, device=dev)
+        ta = _TimeArgs()
+        ta.t, ta.B, ta.ch, ta.tdim = t.data_ptr(), T, ch, tdim
+        ta.w1, ta.b1, ta.w2, ta.b2, ta.hid, ta.act = tw[0].data_ptr(), tw[1].data_ptr(), tw[2].data_ptr(), tw[3].data_ptr(), hid.data_ptr(), act.data_ptr()
+        rc = lib.ctdd_unet_time(C.byref(ta), pw.data_ptr(), pb.data_ptr(), Ntot, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise native.CtddError(f"ctdd_unet_time failed ({rc}): {lib.ctdd_last_error().decode()}")
+        return out
+
+    def __call__(self, x, times, logits_bf16=False, uniform_time=False, slot=None, time_row=None):
         """logits_bf16: write the (B, D, S) logits in bf16 (bf16 engine with the `logits` head; ignored otherwise).
         uniform_time: the caller guarantees that every entry of `times` is the same value (the sampler loops): the time path
         runs once, as one launch, for times[0].
@@ -583,7 +628,7 @@ class UNetEngine:
         `slot` has buffers of its own and replays on the caller's current stream, with no sub-batch split in here."""
         B = x.shape[0]
         lb = bool(logits_bf16) and not self.precise and self.cfg.model.model_output == "logits"
-        ut = bool(uniform_time)
+        ut = "row" if time_row is not None else bool(uniform_time)          # (time_row: the row of time_table() for this call's time)
         ver = self._weights_version()
         if ver != self._wver:                     # weights changed (optimizer step, EMA swap): re-pack
             self._plans.clear()
@@ -602,7 +647,7 @@ class UNetEngine:
                 C_, H_, W_ = self.cfg.data.shape
                 logits = torch.empty((B, C_ * H_ * W_, self.net.S), dtype=torch.bfloat16 if lb else torch.float32, device=self.dev)
                 subs = [self._prepare(Bs, x.dtype, xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs], logits[i * Bs:(i + 1) * Bs],
-                                      logits_bf16=lb, uniform_t=ut) for i in range(nsub)]
+                                      logits_bf16=lb, uniform_t=ut, time_row=time_row) for i in range(nsub)]
                 grp = self._plans[key] = (logits, subs, [torch.cuda.Stream(device=self.dev) for _ in range(nsub - 1)])
             logits, subs, streams = grp
             if all(s.graph is not None for s in subs):
@@ -613,20 +658,20 @@ class UNetEngine:
                 for i in range(1, nsub):
                     with torch.cuda.stream(streams[i - 1]):
                         streams[i - 1].wait_event(ready)
-                        self._replay(subs[i], xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs])
+                        self._replay(subs[i], xs[i * Bs:(i + 1) * Bs], times[i * Bs:(i + 1) * Bs], time_row)
                         ev = torch.cuda.Event()
                         ev.record(streams[i - 1])
                         done.append(ev)
-                self._replay(subs[0], xs[:Bs], times[:Bs])
+                self._replay(subs[0], xs[:Bs], times[:Bs], time_row)
                 for ev in done:
                     main.wait_event(ev)
                 return logits
         key = (B, x.dtype, ut, lb) if slot is None else (B, x.dtype, "slot", int(slot), ut, lb)
         st = self._plans.get(key)
         if st is None:
-            st = self._plans[key] = self._prepare(B, x.dtype, x, times, logits_bf16=lb, uniform_t=ut)
+            st = self._plans[key] = self._prepare(B, x.dtype, x, times, logits_bf16=lb, uniform_t=ut, time_row=time_row)
         st.x_in.copy_(x.reshape(st.x_in.shape))
-        st.t_in.copy_(times.float())
+        self._set_time(st, times, time_row)
         if st.graph is not None:
             st.graph.replay()
         else:

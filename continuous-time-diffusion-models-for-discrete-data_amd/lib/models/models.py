@@ -168,6 +168,20 @@ class ImageX0PredBasePaul(nn.Module):
             return False
         return True
 
+    _engine_int32_states = True          # forward() takes the samplers' int32 states without a widening copy (the engine's plans do)
+
+    def engine_time_table(self, times):
+        """Sampler hook: (T,) grid times -> (T, Ntot) time-projection rows of the HIP inference plan (UNetEngine.time_table), or None
+        when forwards on this device do not go through that plan.  While `_engine_time_row` holds row i, a forward at time
+        times[i] skips the time path (set and cleared by the sampler loop around its network calls)."""
+        probe = torch.zeros((1, 1), dtype=torch.int64, device=times.device)
+        if torch.is_grad_enabled() or not self._use_engine(probe):
+            return None
+        from ctdd import unet_engine
+        if self._engine is None:
+            self._engine = unet_engine.UNetEngine(self)
+        return self._engine.time_table(times)
+
     def _engine_forward(self, x, times):
         from ctdd import unet_engine
         if self._engine is None:
@@ -184,7 +198,8 @@ class ImageX0PredBasePaul(nn.Module):
                     inner._engine_hook = None
             return self._engine.train_forward(x, times)
         out = self._engine(x, times, logits_bf16=bool(getattr(self, "_engine_logits_bf16", False)),
-                           uniform_time=bool(getattr(self, "_engine_uniform_time", False)), slot=getattr(self, "_engine_slot", None))
+                           uniform_time=bool(getattr(self, "_engine_uniform_time", False)), slot=getattr(self, "_engine_slot", None),
+                           time_row=getattr(self, "_engine_time_row", None))
         # the plan owns its output buffer: hand out a copy unless the caller (a sampler loop that consumes the
         # logits before the next forward) asked to borrow it -- two live results must not alias
         return out if getattr(self, "_borrow_engine_output", False) else out.clone()

@@ -122,7 +122,8 @@ class _GridSampler:
     @staticmethod
     def _net_logits(model, x, t, fast=None):
         """model(x, t) as the step kernels take it: bf16 straight through to the bf16 step (fast.bf16), fp32 otherwise."""
-        out = model(x.long(), t)
+        # (the step kernels hand back int32 states; the U-Net engine's plans take them as they are -- no widening pass per step)
+        out = model(x if (x.dtype == torch.int32 and getattr(model, "_engine_int32_states", False)) else x.long(), t)
         if out.dtype == torch.bfloat16 and fast is not None and fast.bf16:
             return out.contiguous()
         return out.float().contiguous()
@@ -197,6 +198,11 @@ class TauL(_GridSampler):
         st.ts = np.concatenate((np.linspace(self.max_t, self.min_t, self.num_steps), np.array([0])))
         st.t32, st.qt0, st.betas = self._tables(model, st.ts[:-1])
         st.fast = self._fast_tables(model, st.qt0)
+        # the grid's times are known here: the U-Net engine computes every step's time-projection row in one launch and the
+        # per-step plans run without their time path (cfg.sampler.time_table, default True; None: the model has no such plan)
+        tt = getattr(model, "engine_time_table", None) if getattr(self.cfg.sampler, "time_table", True) else None
+        st.t_dev = st.t32.to(dev)
+        st.temb = tt(st.t_dev) if tt is not None else None
         st.changed = torch.zeros(self.num_steps, dtype=torch.int32, device=dev)
         st.flags = native.STEP_ORDINAL if self.is_ordinal else 0
         st.sub = 1 + max(int(self.num_corrector_steps), 0)
@@ -224,12 +230,14 @@ class TauL(_GridSampler):
 
     def advance(self, st, i):
         """Step i of the grid: network forward, fused reverse-rate/jump/update launch, correctors."""
-        with self._borrow(st.model):
-            if st.parts == 1:
-                st.x = self._advance_one(st, i, st.x, st.N, st.key, st.changed[i:i + 1])
-                return
-            model = st.model
+        model = st.model
+        with self._borrow(model):
             try:
+                if st.temb is not None:
+                    model._engine_time_row = st.temb[i]
+                if st.parts == 1:
+                    st.x = self._advance_one(st, i, st.x, st.N, st.key, st.changed[i:i + 1])
+                    return
                 for j in range(st.parts):
                     with torch.cuda.stream(st.streams[j]):
                         model._engine_slot = j
@@ -237,12 +245,15 @@ class TauL(_GridSampler):
                         st.xs[j] = self._advance_one(st, i, st.xs[j], st.N // st.parts, st.key + 7919 * j, st.changed_p[j, i:i + 1])
             finally:
                 model._engine_slot = None
+                if st.temb is not None:
+                    model._engine_time_row = None
 
     def _advance_one(self, st, i, x, N, key, changed):
         model = st.model
         t = st.ts[i]
         h = float(np.float32(st.ts[i] - st.ts[i + 1]))
-        t_ones = self._t_ones(st.t32, i, N, st.dev)
+        # (with the time table the plans never read the times: a stride-0 view of the grid value instead of a fill launch per step)
+        t_ones = st.t_dev[i].expand(N) if st.temb is not None else self._t_ones(st.t32, i, N, st.dev)
         q_i = st.qt0[i] if st.qt0 is not None else None
         logits = self._net_logits(model, x, t_ones, st.fast)
         x = self._leap(model, logits, x, q_i, st.fast, i, st.betas[i], h, st.flags, key, i * st.sub, changed=changed)

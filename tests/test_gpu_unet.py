@@ -343,3 +343,47 @@ def test_engine_uniform_time_plan_matches_the_general_plan():
         # (the time path is fp32 in both plans and differs in summation order only; downstream the bf16 activations amplify
         #  that to a few 1e-3 of the logit range -- the bf16 mode's own bar against the fp32 module is 5e-2)
         assert float((uni - general).abs().max()) < 2e-2 * scale, float((uni - general).abs().max()) / scale
+
+
+def test_engine_time_table_rows_replace_the_time_path():
+    """UNetEngine.time_table: all grid times in one launch; a forward that is handed row i (the samplers' loops do, through
+    `model._engine_time_row`) gives the logits of the general plan at time i -- and the table's rows are the projections the
+    module itself computes (fp32 on both sides: 1e-5)."""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from lib.models.models import borrow_engine_output, unwrap
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.device = "cuda"
+    torch.manual_seed(1)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    ts = torch.tensor([0.93, 0.37, 0.011, 1.0], device="cuda")
+    with torch.no_grad():
+        table = model.engine_time_table(ts)
+        net = unwrap(model.net)
+        blocks = [mod.resblocks for mod in list(net.down) + list(net.mid) + list(net.up) if hasattr(mod, "resblocks")]
+        act = torch.nn.functional.silu(net.time(ts))
+        want = torch.cat([rb.time[1](act) for rb in blocks], 1)
+    assert table.shape == want.shape
+    assert float((table - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for B, i in ((5, 1), (64, 0)):
+        x = torch.randint(0, 256, (B, 784), device="cuda", generator=g)
+        t = torch.full((B,), float(ts[i]), device="cuda")
+        with torch.no_grad():
+            general = model(x, t)
+            with borrow_engine_output(model, uniform_time=True):
+                model._engine_time_row = table[i]
+                try:
+                    row = model(x, t).clone()
+                finally:
+                    model._engine_time_row = None
+        scale = float(general.abs().max())
+        assert float((row - general).abs().max()) < 2e-2 * scale, float((row - general).abs().max()) / scale    # (as the uniform-time plan)
+    # a plan built for rows refuses a call without one instead of running on a stale row
+    from ctdd import native
+    eng = model._engine
+    st = next(v for k, v in eng._plans.items() if "row" in k and not isinstance(v, tuple))
+    with pytest.raises(native.CtddError):
+        eng._set_time(st, t, None)
