@@ -1635,6 +1635,102 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnArgs a) {
   }
 }
 
+// GroupNorm (+ Swish) of bf16 tensors in ONE pass over memory: a workgroup owns (sample, slab of whole groups), reads the slab's
+// HW x slabC values once into registers, reduces their sums / sums of squares across the workgroup (fp32 per thread over <= MAXV
+// pixels, fp64 across threads and group members, like the atomics of the convolution epilogues it replaces), and writes the
+// normalised values from the registers.  No statistics in the producing convolutions' epilogues, no statistics buffers to
+// zero, half the passes over the tensor of k_gn_apply behind a statistics epilogue.
+// Thread t = (pixel lane pl = t / noct, octet oct = t % noct): 8 channels of pixels pl, pl + npl, ...: consecutive lanes read
+// consecutive 16-byte pieces of a pixel's slab, then the next pixel.  The slab may straddle the two concatenated sources
+// (8-channel vectors never do: C1 % 8 == 0).
+template <int MAXV>
+__global__ __launch_bounds__(1024) void k_gn_onepass(const GnArgs a, int slabC, int noct, int npl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  const int C = a.C1 + a.C2, cg = C / a.G, b = blockIdx.y, cs0 = blockIdx.x * slabC, HW = a.HW;
+  const int t = threadIdx.x, T = noct * npl;
+  float* part = (float*)gsm;                                   // [T][16]: sums, sums of squares of the thread's 8 channels
+  double* red = (double*)(gsm + (size_t)T * 64);               // [2][slabC]
+  float* scale = (float*)(red + 2 * slabC);                    // [slabC]
+  float* shift = scale + slabC;
+  const bool act = t < T;
+  const int oct = act ? t % noct : 0, pl = act ? t / noct : 0;
+  const int c0 = cs0 + oct * 8;
+  const bool first = c0 < a.C1;
+  const int Cs = first ? a.C1 : a.C2;
+  const unsigned short* src = (first ? a.s1_bf16 : a.s2_bf16) + (size_t)b * HW * Cs + (first ? c0 : c0 - a.C1);
+  uint4 u[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int p = pl + k * npl;
+    u[k] = (act && p < HW) ? *(const uint4*)(src + (size_t)p * Cs) : make_uint4(0, 0, 0, 0);
+  }
+  float sx[8], sq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sx[j] = 0.0f; sq[j] = 0.0f; }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {                             // (absent pixels are zeros: they add nothing)
+    const unsigned w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = __uint_as_float(w[j] << 16), x1 = __uint_as_float(w[j] & 0xFFFF0000u);
+      sx[2 * j] += x0; sq[2 * j] = fmaf(x0, x0, sq[2 * j]);
+      sx[2 * j + 1] += x1; sq[2 * j + 1] = fmaf(x1, x1, sq[2 * j + 1]);
+    }
+  }
+  if (act) {
+    float4* pt = (float4*)(part + (size_t)t * 16);
+    pt[0] = make_float4(sx[0], sx[1], sx[2], sx[3]); pt[1] = make_float4(sx[4], sx[5], sx[6], sx[7]);
+    pt[2] = make_float4(sq[0], sq[1], sq[2], sq[3]); pt[3] = make_float4(sq[4], sq[5], sq[6], sq[7]);
+  }
+  __syncthreads();
+  for (int r = t; r < 2 * slabC; r += blockDim.x) {            // (moment m, local channel cl): over the pixel lanes, in fp64
+    const int m = r / slabC, cl = r - m * slabC;
+    const float* pp = part + (size_t)(cl >> 3) * 16 + m * 8 + (cl & 7);
+    double acc = 0.0;
+    for (int q = 0; q < npl; ++q) acc += (double)pp[(size_t)q * noct * 16];
+    red[r] = acc;
+  }
+  __syncthreads();
+  for (int cl = t; cl < slabC; cl += blockDim.x) {
+    const int c = cs0 + cl, gl0 = (c / cg) * cg - cs0;          // the group's first channel, local (slabs hold whole groups)
+    double s = 0.0, q = 0.0;
+    for (int j = gl0; j < gl0 + cg; ++j) { s += red[j]; q += red[slabC + j]; }
+    const double n = (double)cg * (double)HW;
+    const double mean = s / n;
+    const double var = fmax(q / n - mean * mean, 0.0);
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    scale[cl] = rstd * a.gamma[c];
+    shift[cl] = a.beta[c] - (float)mean * rstd * a.gamma[c];
+  }
+  __syncthreads();
+  if (!act) return;
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  const float4 sc0 = *(const float4*)(scale + oct * 8), sc1 = *(const float4*)(scale + oct * 8 + 4);
+  const float4 sh0 = *(const float4*)(shift + oct * 8), sh1 = *(const float4*)(shift + oct * 8 + 4);
+  const f2 scv[4] = {{sc0.x, sc0.y}, {sc0.z, sc0.w}, {sc1.x, sc1.y}, {sc1.z, sc1.w}};
+  const f2 shv[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
+  unsigned short* dst = a.out_hi + (size_t)b * HW * C + c0;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int p = pl + k * npl;
+    if (p >= HW) break;
+    const unsigned w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+    unsigned ow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f2 x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+      f2 y = __builtin_elementwise_fma(x, scv[j], shv[j]);
+      if (a.swish) {                                                      // as k_gn_apply: hardware exp2 / rcp
+        const f2 z = y * (f2){-1.4426950408889634f, -1.4426950408889634f};
+        const f2 d = (f2){__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + (f2){1.0f, 1.0f};
+        y = y * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+      }
+      ow[j] = pack2_bf16(y.x, y.y);
+    }
+    *(uint4*)(dst + (size_t)p * C) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
 // per-(b, channel) sum / sumsq of an NHWC tensor (for tensors no conv epilogue produced)
 __global__ __launch_bounds__(256) void k_channel_stats(const float* __restrict__ x, int HW, int C, double* __restrict__ stats) {
   const int b = blockIdx.y;
@@ -2089,6 +2185,60 @@ extern "C" int ctdd_unet_gn_apply(const void* args_, void* stream) {
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(k_gn_apply, dim3(gx, a.B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, a);
   return finish_launch("k_gn_apply");
+}
+
+// slabC: channels per workgroup (a multiple of lcm(C / G, 8) that divides C); 0: chosen here.  max_threads: workgroup size limit
+// (0: 1024).  Returns CTDD_ERANGE when no slab fits the registers (HW * slabC / 8 vectors over <= max_threads threads, <= 12
+// each): the caller then keeps k_gn_apply behind statistics.
+extern "C" int ctdd_unet_gn_onepass(const void* args_, int slabC, int max_threads, void* stream) {
+  if (max_threads <= 0 || max_threads > 1024) max_threads = 1024;
+  const GnArgs& a = *(const GnArgs*)args_;
+  const int C = a.C1 + a.C2;
+  CTDD_REQUIRE(C % 8 == 0 && a.C1 % 8 == 0 && a.G > 0 && C % a.G == 0 && a.out_hi && a.s1_bf16 && (a.C2 == 0 || a.s2_bf16) && a.HW > 0 && a.B > 0,
+               CTDD_EINVAL, "bad one-pass GroupNorm arguments (bf16 sources and output, C %% 8 == 0)");
+  const int cg = C / a.G;
+  int L = cg;
+  while (L % 8) L += cg;                                         // lcm(cg, 8)
+  auto shape = [&](int sc, int& noct, int& npl, int& nvec) {
+    noct = sc / 8;
+    if (noct > max_threads) return false;
+    npl = max_threads / noct < a.HW ? max_threads / noct : a.HW;
+    nvec = (a.HW + npl - 1) / npl;
+    return nvec <= 12;
+  };
+  int noct = 0, npl = 0, nvec = 0;
+  if (slabC <= 0) {
+    // the largest slab that still gives >= 256 workgroups; failing that, the smallest that fits
+    int best = 0;
+    for (int sc = L; sc <= C; sc += L) {
+      if (C % sc) continue;
+      int o, p_, v;
+      if (!shape(sc, o, p_, v)) continue;
+      const long wgs = (long)a.B * (C / sc);
+      if (best == 0 || wgs >= 256) best = sc;
+      if (wgs < 256) break;
+    }
+    slabC = best;
+  }
+  CTDD_REQUIRE(slabC > 0 && slabC % L == 0 && C % slabC == 0 && shape(slabC, noct, npl, nvec), CTDD_ERANGE,
+               "one-pass GroupNorm: no slab of whole groups fits (HW=%d C=%d G=%d slab=%d)", a.HW, C, a.G, slabC);
+  int threads = ((noct * npl + 63) / 64) * 64;
+  const int need = 2 * slabC;                                    // the reduction wants a thread per (moment, channel) at best
+  if (threads < 256) threads = 256;
+  (void)need;
+  const size_t lds = (size_t)noct * npl * 64 + (size_t)2 * slabC * 8 + (size_t)2 * slabC * 4;
+  const dim3 g((unsigned)(C / slabC), (unsigned)a.B);
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_done[4][16] = {};
+  auto go = [&](auto kernel, int slot) {
+    ensure_lds_ceiling((const void*)kernel, attr_done[slot]);
+    hipLaunchKernelGGL(kernel, g, dim3(threads), lds, st, a, slabC, noct, npl);
+  };
+  if (nvec <= 2) go(k_gn_onepass<2>, 0);
+  else if (nvec <= 4) go(k_gn_onepass<4>, 1);
+  else if (nvec <= 8) go(k_gn_onepass<8>, 2);
+  else go(k_gn_onepass<12>, 3);
+  return finish_launch("k_gn_onepass");
 }
 
 extern "C" int ctdd_unet_channel_stats(const float* x, int B, int HW, int C, double* stats, void* stream) {

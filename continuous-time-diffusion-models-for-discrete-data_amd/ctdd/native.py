@@ -66,7 +66,7 @@ _SIGS = {
     "ctdd_grad_sumsq": ([_P, _P, _I, _P, _I, _P], _I),
     "ctdd_adam_ema_apply": ([_P, _P, _I, _F, _F, _F, _F, _I64, _F, _F, _P, _P], _I),
 }
-UNET_EXPORTS = ("ctdd_unet_conv", "ctdd_unet_conv_patch", "ctdd_unet_conv_res", "ctdd_unet_conv_ring", "ctdd_unet_upsample2x", "ctdd_unet_first_conv", "ctdd_unet_gn_apply", "ctdd_unet_channel_stats",
+UNET_EXPORTS = ("ctdd_unet_conv", "ctdd_unet_conv_patch", "ctdd_unet_conv_res", "ctdd_unet_conv_ring", "ctdd_unet_upsample2x", "ctdd_unet_first_conv", "ctdd_unet_gn_apply", "ctdd_unet_gn_onepass", "ctdd_unet_channel_stats",
                 "ctdd_unet_time", "ctdd_unet_time_uniform", "ctdd_unet_attention", "ctdd_unet_logistic_head")    # bound in ctdd/unet_engine.py
 HOLLOW_EXPORTS = ("ctdd_gemm_bf16", "ctdd_hollow_small_linear", "ctdd_hollow_embed", "ctdd_hollow_layernorm", "ctdd_hollow_add", "ctdd_hollow_put_rows", "ctdd_hollow_attention", "ctdd_hollow_attention_bf16")
 UNET_TRAIN_EXPORTS = ("ctdd_unet_wgrad", "ctdd_unet_gn_bwd", "ctdd_unet_dropout", "ctdd_unet_colsum", "ctdd_unet_sum_batch", "ctdd_unet_sum_jobs", "ctdd_unet_accumulate",

@@ -68,7 +68,7 @@ def _lib():
     if not _sigs_done:
         for name, argt in (("ctdd_unet_conv", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_patch", [_P, _I, _I, _I, _P]), ("ctdd_unet_conv_res", [_P, _I, _P]), ("ctdd_unet_conv_ring", [_P, _I, _P]),
                            ("ctdd_unet_upsample2x", [_P, _I, _I, _I, _I, _P, _P]), ("ctdd_unet_first_conv", [_P, _P]),
-                           ("ctdd_unet_gn_apply", [_P, _P]), ("ctdd_unet_channel_stats", [_P, _I, _I, _I, _P, _P]),
+                           ("ctdd_unet_gn_apply", [_P, _P]), ("ctdd_unet_gn_onepass", [_P, _I, _I, _P]), ("ctdd_unet_channel_stats", [_P, _I, _I, _I, _P, _P]),
                            ("ctdd_unet_time", [_P, _P, _P, _I, _P, _P]), ("ctdd_unet_time_uniform", [_P, _P, _P, _I, _P, _P]),
                            ("ctdd_unet_attention", [_P, _P]),
                            ("ctdd_unet_logistic_head", [_P, _P])):
@@ -99,6 +99,36 @@ def training_supported(model):
     return net.channel % 16 == 0 and all((net.channel * int(m_)) % 16 == 0 for m_ in model.cfg.model.ch_mult)
 
 
+class _GnUncovered(Exception):
+    """A GroupNorm shape outside k_gn_onepass (UNetEngine._build falls back to statistics epilogues + k_gn_apply)."""
+
+
+def _onepass_slab(B, HW, Cn, G, max_threads=1024):
+    """Channels per workgroup ctdd_unet_gn_onepass will choose (csrc/unet_kernels.hip), 0 when no slab of whole groups fits."""
+    if Cn % 8 or G <= 0 or Cn % G:
+        return 0
+    cg = Cn // G
+    L = cg
+    while L % 8:
+        L += cg
+    best = 0
+    for sc in range(L, Cn + 1, L):
+        if Cn % sc:
+            continue
+        noct = sc // 8
+        if noct > max_threads:
+            continue
+        npl = min(max_threads // noct, HW)
+        if -(-HW // npl) > 12:
+            continue
+        wgs = B * (Cn // sc)
+        if best == 0 or wgs >= 256:
+            best = sc
+        if wgs < 256:
+            break
+    return best
+
+
 class _Tensor:
     """NHWC activation [B*H*W][C]: bf16 (`hi`) in bf16 mode, fp32 (`f32`) in fp32 mode, plus the offset
     of its per-(b, channel) statistics in the plan's pool."""
@@ -108,7 +138,7 @@ class _Tensor:
         self.B, self.H, self.W, self.C = B, H, W, Cn
         self.f32 = torch.empty((M, Cn), dtype=torch.float32, device=dev) if eng.precise else None
         self.hi = None if eng.precise else torch.empty((M, Cn), dtype=torch.bfloat16, device=dev)
-        self.stats = eng.alloc_stats(B * Cn * 2) if stats else None
+        self.stats = eng.alloc_stats(B * Cn * 2) if (stats and not H * W <= getattr(eng, "_plan_no_stats_hw", 0)) else None
         eng._live.append(self)           # raw pointers are baked into the plan: keep every buffer alive
 
 
@@ -166,7 +196,23 @@ class UNetEngine:
         return off
 
     def _build(self, B, x_dtype, logits_out=None, tc=None, logits_bf16=False, uniform_t=False):
+        # bf16 inference plans: GroupNorm as one pass per tensor with the statistics inside (k_gn_onepass), no statistics in
+        # the convolution epilogues (cfg.model.gn_onepass, default on); a net with a GroupNorm the kernel does not cover is
+        # rebuilt the old way (statistics by the producers, k_gn_apply)
+        if (not self.precise) and tc is None and int(getattr(self.cfg.model, "gn_onepass", 1)):
+            try:
+                return self._build_impl(B, x_dtype, logits_out, tc, logits_bf16, uniform_t, onepass_gn=True)
+            except _GnUncovered:
+                pass
+        return self._build_impl(B, x_dtype, logits_out, tc, logits_bf16, uniform_t, onepass_gn=False)
+
+    def _build_impl(self, B, x_dtype, logits_out=None, tc=None, logits_bf16=False, uniform_t=False, onepass_gn=False):
         net, m = self.net, self.cfg.model
+        # (levels up to gn_onepass_max_hw pixels per sample: above it the one-workgroup-per-(sample, slab) kernel loses to the many
+        #  small workgroups of k_gn_apply, and those tensors keep their statistics epilogues.  MNIST net, batch 256, sampler loop:
+        #  off 85.1 k sample-steps/s, 7x7 only 85.8 k, 7x7 + 14x14 87.9 k, all levels 85.1 k)
+        self._plan_no_stats_hw = int(getattr(m, "gn_onepass_max_hw", 256)) if onepass_gn else 0
+        gn_threads = int(getattr(m, "gn_threads", 512))    # (measured in the two-chain sampler loop: 384-512 best, 1024 -1 %)
         lib = _lib()
         dev = self.dev
         Cin, H0, W0 = self.cfg.data.shape
@@ -331,17 +377,28 @@ class UNetEngine:
             a = _GnArgs()
             s1 = srcs[0]
             a.s1_f32, a.s1_bf16, a.C1 = (ptr(s1.f32), None, s1.C) if self.precise else (None, ptr(s1.hi), s1.C)
-            stats_views.append((a, s1.stats, "st1"))
+            if s1.stats is not None:
+                stats_views.append((a, s1.stats, "st1"))
             if len(srcs) == 2:
                 s2 = srcs[1]
                 a.s2_f32, a.s2_bf16, a.C2 = (ptr(s2.f32), None, s2.C) if self.precise else (None, ptr(s2.hi), s2.C)
-                stats_views.append((a, s2.stats, "st2"))
+                if s2.stats is not None:
+                    stats_views.append((a, s2.stats, "st2"))
             g, b_ = norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous()
             keep.extend([g, b_, a, out])
             a.gamma, a.beta = ptr(g), ptr(b_)
             a.B, a.HW, a.G, a.eps, a.swish = B, HW, norm.num_groups, eps, int(swish)
             a.out_hi, a.out_f32 = ptr(out.hi), ptr(out.f32)
-            launch(lib.ctdd_unet_gn_apply, C.byref(a), label=f"gn {srcs[0].H}x{srcs[0].W} C={Ct} ({len(srcs)} src)")
+            if onepass_gn and HW > self._plan_no_stats_hw:
+                launch(lib.ctdd_unet_gn_apply, C.byref(a), label=f"gn {srcs[0].H}x{srcs[0].W} C={Ct} ({len(srcs)} src)")
+            elif onepass_gn and _onepass_slab(B, HW, Ct, norm.num_groups, gn_threads) > 0:
+                # inference, bf16: statistics + normalisation in one pass over the tensor (k_gn_onepass); the producers' epilogues
+                # then carry no statistics at all (their tensors were created without statistics buffers)
+                launch(lib.ctdd_unet_gn_onepass, C.byref(a), 0, gn_threads, label=f"gn1 {srcs[0].H}x{srcs[0].W} C={Ct} ({len(srcs)} src)")
+            else:
+                if onepass_gn:
+                    raise _GnUncovered(f"one-pass GroupNorm does not cover HW={HW} C={Ct} G={norm.num_groups}")
+                launch(lib.ctdd_unet_gn_apply, C.byref(a), label=f"gn {srcs[0].H}x{srcs[0].W} C={Ct} ({len(srcs)} src)")
             if tc is not None:
                 tc.record_gn(srcs, norm, swish, eps, HW, out, drop_p, launch, stats_views)
             return out
@@ -397,7 +454,8 @@ class UNetEngine:
         if logistic:
             st.x0 = torch.empty((B, Cin, H0, W0), dtype=torch.float32, device=dev)
             fa.x0_f32 = ptr(st.x0)
-        stats_views.append((fa, cur.stats))
+        if cur.stats is not None:
+            stats_views.append((fa, cur.stats))
         keep.extend([w0, b0, fa])
         launch(lib.ctdd_unet_first_conv, C.byref(fa))
         if tc is not None:

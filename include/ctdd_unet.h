@@ -65,6 +65,11 @@ typedef struct {
 } ctdd_gn_args;
 /* GroupNorm (+Swish) of the channel concatenation of one or two tensors (unet.py:103-133, 403-416) */
 int ctdd_unet_gn_apply(const void* gn_args, void* stream);
+/* The same normalisation of bf16 tensors in one pass over memory, statistics included (st1 / st2 are not read): a workgroup owns
+ * (sample, slab of whole groups) and holds it in registers between the reduction and the write.  slab_channels: a multiple of
+ * lcm(C / G, 8) dividing C, or 0 to let the library choose; max_threads: workgroup size limit (0: 1024); CTDD_ERANGE when no slab
+ * fits (fall back to ctdd_unet_gn_apply). */
+int ctdd_unet_gn_onepass(const void* gn_args, int slab_channels, int max_threads, void* stream);
 int ctdd_unet_channel_stats(const float* x, int B, int HW, int C, double* stats, void* stream);
 
 typedef struct {

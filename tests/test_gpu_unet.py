@@ -387,3 +387,85 @@ def test_engine_time_table_rows_replace_the_time_path():
     st = next(v for k, v in eng._plans.items() if "row" in k and not isinstance(v, tuple))
     with pytest.raises(native.CtddError):
         eng._set_time(st, t, None)
+
+
+@pytest.mark.parametrize("B,H,C1,C2,G,swish,slab", [
+    (5, 28, 96, 0, 32, 1, 0), (3, 28, 192, 96, 32, 1, 0), (4, 14, 192, 192, 32, 1, 0), (7, 7, 192, 0, 32, 0, 0),
+    (2, 28, 96, 96, 32, 1, 96), (130, 7, 192, 192, 32, 1, 0), (2, 4, 64, 0, 32, 1, 0), (3, 32, 128, 0, 32, 1, 0), (2, 14, 96, 0, 32, 1, 24)])
+def test_gn_onepass_matches_groupnorm(B, H, C1, C2, G, swish, slab):
+    """ctdd_unet_gn_onepass (statistics + GroupNorm + Swish of bf16 NHWC tensors in one pass, one or two concatenated sources,
+    slabs of whole groups -- including groups and slabs that straddle the two sources) against torch's GroupNorm in fp32 on the
+    same bf16-rounded values; the result is bf16: 2^-8 relative + the hardware exp2 / rcp of the Swish."""
+    import ctypes as C_
+    from ctdd import unet_engine as ue
+    lib = ue._lib()
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + C1)
+    HW, Ct = H * H, C1 + C2
+    srcs = [(torch.randn((B, HW, c), device="cuda", generator=g) * 1.7 + 0.4).to(torch.bfloat16) for c in (C1, C2) if c]
+    gamma = torch.randn(Ct, device="cuda", generator=g)
+    beta = torch.randn(Ct, device="cuda", generator=g)
+    out = torch.zeros((B, HW, Ct), dtype=torch.bfloat16, device="cuda")
+    a = ue._GnArgs()
+    a.s1_bf16, a.C1 = srcs[0].data_ptr(), C1
+    if C2:
+        a.s2_bf16, a.C2 = srcs[1].data_ptr(), C2
+    a.gamma, a.beta, a.B, a.HW, a.G, a.eps, a.swish, a.out_hi = gamma.data_ptr(), beta.data_ptr(), B, HW, G, 1e-5, swish, out.data_ptr()
+    rc = lib.ctdd_unet_gn_onepass(C_.byref(a), slab, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.ctdd_last_error().decode()
+    assert ue._onepass_slab(B, HW, Ct, G) > 0
+    x = torch.cat([s_.float() for s_ in srcs], 2).permute(0, 2, 1).reshape(B, Ct, H, H)
+    want = torch.nn.functional.group_norm(x, G, gamma, beta, 1e-5)
+    if swish:
+        want = want * torch.sigmoid(want)
+    want = want.reshape(B, Ct, HW).permute(0, 2, 1)
+    err = (out.float() - want).abs()
+    assert float((err - 2.0 ** -7 * want.abs()).max()) <= 2e-3, float(err.max())
+
+
+def test_gn_onepass_refuses_what_it_cannot_hold():
+    import ctypes as C_
+    from ctdd import unet_engine as ue
+    lib = ue._lib()
+    x = torch.zeros((1, 64 * 64, 256), dtype=torch.bfloat16, device="cuda")      # 64x64 x (8 channels per group, slab >= 8): 4096 pixels / 1024 lanes > ... fits; G = 1 does not
+    out = torch.empty_like(x)
+    w = torch.ones(256, device="cuda")
+    a = ue._GnArgs()
+    a.s1_bf16, a.C1, a.gamma, a.beta, a.B, a.HW, a.G, a.eps, a.swish, a.out_hi = x.data_ptr(), 256, w.data_ptr(), w.data_ptr(), 1, 4096, 1, 1e-5, 1, out.data_ptr()
+    assert lib.ctdd_unet_gn_onepass(C_.byref(a), 0, 0, torch.cuda.current_stream().cuda_stream) != 0      # one group of 256 channels x 4096 pixels: 128 vectors per lane
+    assert ue._onepass_slab(1, 4096, 256, 1) == 0
+
+
+def test_engine_onepass_groupnorm_plans_match_statistics_epilogue_plans():
+    """cfg.model.gn_onepass (default on: the 7x7 / 14x14 levels' GroupNorms as one launch with the statistics inside, no
+    statistics in their producers' epilogues) against the plan with statistics epilogues + k_gn_apply everywhere, and both
+    against the fp32 module at the bf16 bar.  (The one-pass statistics are those of the bf16-rounded tensor the kernel
+    normalises; the epilogue statistics those of the fp32 accumulators before rounding.)"""
+    import lib.models.models  # noqa: F401
+    import lib.models.model_utils as mu
+    from ctdd.unet_engine import UNetEngine
+    from config.mnist_config.config_tauUnet_mnist import get_config
+    cfg = get_config()
+    cfg.device = "cuda"
+    cfg.model.engine = "torch"
+    torch.manual_seed(2)
+    model = mu.create_model(cfg, torch.device("cuda"))
+    model.eval()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randint(0, 256, (48, 784), device="cuda", generator=g)
+    t = torch.rand(48, device="cuda", generator=g) * 0.98 + 0.01
+    with torch.no_grad():
+        want = model(x, t)
+    outs = {}
+    for flag in (1, 0):
+        cfg.model.gn_onepass = flag
+        eng = UNetEngine(model, precision="bf16")
+        with torch.no_grad():
+            outs[flag] = eng(x, t).float().clone()
+        labels = [getattr(s_, "label", "") or "" for v in eng._plans.values() for s_ in (v.plan if not isinstance(v, tuple) else [p_ for sub in v[1] for p_ in sub.plan])]
+        fns = [lb[0] for lb in labels if isinstance(lb, tuple)]                 # (entry point, label) per launch
+        n1, n0 = fns.count("ctdd_unet_gn_onepass"), fns.count("ctdd_unet_gn_apply")
+        assert (n1 > 0 and n0 > 0) if flag else (n1 == 0 and n0 > 0), (flag, n1, n0)      # small levels one-pass, 28x28 the statistics path
+    scale = float(want.abs().max())
+    for flag in (1, 0):
+        assert float((outs[flag] - want).abs().max()) < 5e-2 * scale
+    assert float((outs[1] - outs[0]).abs().max()) < 2e-2 * scale
