@@ -531,6 +531,134 @@ __global__ __launch_bounds__(256) void k_gn_bwd_dx(const GnBwdArgs a) {
   }
 }
 
+// The same backward in ONE launch for bf16 tensors (round 3): a workgroup owns (sample, slab of whole groups) -- everything the
+// two group means need -- and keeps the slab's x and dz in registers between the sums and dX.  The slab is 24-96 channels
+// wide (48-192 contiguous bytes per pixel and lane group, not the 16 bytes per row the note above measured), and the slabs
+// of one sample are placed on one XCD (blockIdx.x = sample, a multiple-of-8 batch), so its rows cross the fabric once.
+// Thread t = (pixel lane pl = t / noct, octet oct = t % noct); pixels pl, pl + npl, ...  `sums` are plain stores here.
+template <int MAXV>
+__global__ __launch_bounds__(512) void k_gn_bwd_onepass(const GnBwdArgs a, int slabC, int noct, int npl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  const int C = a.C1 + a.C2, cg = C / a.G, b = blockIdx.x, cs0 = blockIdx.y * slabC, HW = a.HW;
+  const int t = threadIdx.x, T = noct * npl;
+  float* part = (float*)gsm;                                   // [T][16]
+  float* tab = part + (size_t)T * 16;                          // mean, rstd, gamma, beta, S1, S2, m1, m2: [8][slabC]
+  const bool act = t < T;
+  const int oct = act ? t % noct : 0, pl = act ? t / noct : 0;
+  const int c0 = cs0 + oct * 8;
+  const bool first = c0 < a.C1;
+  const int cc = first ? c0 : c0 - a.C1, Cs = first ? a.C1 : a.C2;
+  const unsigned short* xs = (first ? a.s1_bf16 : a.s2_bf16) + (size_t)b * HW * Cs + cc;
+  const unsigned short* das = a.da_bf16 + (size_t)b * HW * C + c0;
+  unsigned short* const dh = (first ? a.d1_bf16 : a.d2_bf16) + (size_t)b * HW * Cs + cc;
+  const bool accum = first ? a.acc1 : a.acc2;
+  uint4 ux[MAXV], ud[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int p = pl + k * npl;
+    const bool ok = act && p < HW;
+    ux[k] = ok ? *(const uint4*)(xs + (size_t)p * Cs) : make_uint4(0, 0, 0, 0);
+    ud[k] = ok ? *(const uint4*)(das + (size_t)p * C) : make_uint4(0, 0, 0, 0);
+  }
+  for (int cl = t; cl < slabC; cl += blockDim.x) {             // statistics of the forward (fp64 sums of the producers' epilogues)
+    const int c = cs0 + cl, gl = (c / cg) * cg;
+    double s = 0.0, q = 0.0;
+    for (int jc = gl; jc < gl + cg; ++jc) {
+      const double* st = jc < a.C1 ? a.st1 + ((size_t)b * a.C1 + jc) * 2 : a.st2 + ((size_t)b * a.C2 + (jc - a.C1)) * 2;
+      s += st[0]; q += st[1];
+    }
+    const double n = (double)cg * (double)HW, m = s / n, var = fmax(q / n - m * m, 0.0);
+    tab[cl] = (float)m;
+    tab[slabC + cl] = (float)(1.0 / sqrt(var + (double)a.eps));
+    tab[2 * slabC + cl] = a.gamma[c];
+    tab[3 * slabC + cl] = a.beta[c];
+  }
+  __syncthreads();
+  float tm[8], tr[8], tg[8], tb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    tm[j] = tab[oct * 8 + j]; tr[j] = tab[slabC + oct * 8 + j]; tg[j] = tab[2 * slabC + oct * 8 + j]; tb[j] = tab[3 * slabC + oct * 8 + j];
+  }
+  float dzv[MAXV][8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.0f; s2[j] = 0.0f; }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int p = pl + k * npl;
+    if (act && p < HW) {
+      GnVecRaw r;
+      const unsigned wx[4] = {ux[k].x, ux[k].y, ux[k].z, ux[k].w}, wd[4] = {ud[k].x, ud[k].y, ud[k].z, ud[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.x[2 * j] = bf_lo(wx[j]); r.x[2 * j + 1] = bf_hi(wx[j]);
+        r.da[2 * j] = bf_lo(wd[j]); r.da[2 * j + 1] = bf_hi(wd[j]);
+      }
+      r.oo = ((size_t)b * HW + p) * C + c0;
+      float xh[8];
+      gn_bwd_math(a, tm, tr, tg, tb, r, dzv[k], xh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += dzv[k][j]; s2[j] = fmaf(dzv[k][j], xh[j], s2[j]); }
+      if (accum) ud[k] = *(const uint4*)(dh + (size_t)p * Cs);               // the gradient already there: in flight under the reductions
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dzv[k][j] = 0.0f;
+    }
+  }
+  if (act) {
+    float4* pt = (float4*)(part + (size_t)t * 16);
+    pt[0] = make_float4(s1[0], s1[1], s1[2], s1[3]); pt[1] = make_float4(s1[4], s1[5], s1[6], s1[7]);
+    pt[2] = make_float4(s2[0], s2[1], s2[2], s2[3]); pt[3] = make_float4(s2[4], s2[5], s2[6], s2[7]);
+  }
+  __syncthreads();
+  for (int r = t; r < 2 * slabC; r += blockDim.x) {
+    const int which = r / slabC, cl = r - which * slabC;
+    const float* pp = part + (size_t)(cl >> 3) * 16 + which * 8 + (cl & 7);
+    float acc = 0.0f;
+    for (int q = 0; q < npl; ++q) acc += pp[(size_t)q * noct * 16];
+    tab[(4 + which) * slabC + cl] = acc;
+    a.sums[((size_t)b * C + cs0 + cl) * 2 + which] = acc;      // (sole owner of these entries: no atomics)
+  }
+  __syncthreads();
+  for (int cl = t; cl < slabC; cl += blockDim.x) {
+    const int c = cs0 + cl, gl = (c / cg) * cg - cs0;
+    float t1 = 0.0f, t2 = 0.0f;
+    for (int jc = gl; jc < gl + cg; ++jc) { t1 = fmaf(tab[2 * slabC + jc], tab[4 * slabC + jc], t1); t2 = fmaf(tab[2 * slabC + jc], tab[5 * slabC + jc], t2); }
+    const float inv = 1.0f / ((float)cg * (float)HW);
+    tab[6 * slabC + cl] = t1 * inv; tab[7 * slabC + cl] = t2 * inv;
+  }
+  __syncthreads();
+  if (a.dsum_bn || a.dsum_n) {                                  // closed-form per-sample sums of dX (as k_gn_bwd_dx)
+    for (int cl = t; cl < slabC; cl += blockDim.x) {
+      const int c = cs0 + cl;
+      if (c >= a.C1) continue;
+      const float sx = (float)a.st1[((size_t)b * a.C1 + c) * 2];
+      const float sxh = (sx - (float)HW * tab[cl]) * tab[slabC + cl];
+      const float val = tab[slabC + cl] * (tab[2 * slabC + cl] * tab[4 * slabC + cl] - (float)HW * tab[6 * slabC + cl] - tab[7 * slabC + cl] * sxh);
+      if (a.dsum_bn) a.dsum_bn[(size_t)b * a.dsum_stride + c] = val;
+      if (a.dsum_n) atomicAdd(a.dsum_n + c, val);
+    }
+  }
+  if (!act) return;
+  float sc[8], k1[8], k2[8];                                       // dX = sc dz - k1 - xhat k2
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = tr[j] * tg[j]; k1[j] = tr[j] * tab[6 * slabC + oct * 8 + j]; k2[j] = tr[j] * tab[7 * slabC + oct * 8 + j]; }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int p = pl + k * npl;
+    if (p >= HW) break;
+    const unsigned wx[4] = {ux[k].x, ux[k].y, ux[k].z, ux[k].w}, wo[4] = {ud[k].x, ud[k].y, ud[k].z, ud[k].w};
+    float dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (j & 1) ? bf_hi(wx[j >> 1]) : bf_lo(wx[j >> 1]);
+      const float xh = (x - tm[j]) * tr[j];
+      dx[j] = fmaf(-xh, k2[j], fmaf(sc[j], dzv[k][j], -k1[j]));
+      if (accum) dx[j] += (j & 1) ? bf_hi(wo[j >> 1]) : bf_lo(wo[j >> 1]);
+    }
+    *(uint4*)(dh + (size_t)p * Cs) = make_uint4(pack2_bf16(dx[0], dx[1]), pack2_bf16(dx[2], dx[3]), pack2_bf16(dx[4], dx[5]), pack2_bf16(dx[6], dx[7]));
+  }
+}
+
 // forward-side dropout of an activated tensor in place (the mask backward regenerates): a *= keep / (1 - p)
 __global__ __launch_bounds__(256) void k_dropout(float* f, unsigned short* h, int64_t nvec, float p, const uint64_t* rng, uint64_t layer) {
   const float inv_keep = 1.0f / (1.0f - p);
@@ -933,10 +1061,44 @@ extern "C" int ctdd_unet_gn_bwd(const void* args_, void* stream) {
   CTDD_REQUIRE((a.s1_f32 || a.s1_bf16) && (a.da_f32 || a.da_bf16) && (a.d1_f32 || a.d1_bf16), CTDD_EINVAL, "gn bwd: null tensor");
   CTDD_REQUIRE(!(a.dsum_bn || a.dsum_n) || a.C2 == 0, CTDD_EINVAL, "gn bwd: per-sample sums of dX are for a single source");
   CTDD_REQUIRE(a.drop_p >= 0.0f && a.drop_p < 1.0f && (a.drop_p == 0.0f || a.rng), CTDD_EINVAL, "gn bwd: dropout p=%g", (double)a.drop_p);
+  hipStream_t st = (hipStream_t)stream;
+  // bf16 tensors: one launch, a workgroup per (sample, slab of whole groups) when such a slab fits the registers
+  // (<= 8 vectors of 8 channels per thread at <= 512 threads); CTDD_GN_BWD_TWO_PASS=1 keeps the two launches (A/B runs)
+  static const bool two_pass = [] { const char* e = getenv("CTDD_GN_BWD_TWO_PASS"); return e && e[0] == '1'; }();
+  if (!two_pass && a.s1_bf16 && (a.C2 == 0 || a.s2_bf16) && a.da_bf16 && a.d1_bf16 && (a.C2 == 0 || a.d2_bf16) && !a.s1_f32 && !a.da_f32 &&
+      !a.d1_f32 && !a.d2_f32) {
+    const int cg = C / a.G;
+    int L = cg;
+    while (L % 8) L += cg;
+    int best = 0, bo = 0, bp = 0, bv = 0;
+    for (int sc = L; sc <= C; sc += L) {
+      if (C % sc) continue;
+      const int noct = sc / 8;
+      if (noct > 512) break;
+      const int npl = 512 / noct < a.HW ? 512 / noct : a.HW, nvec = (a.HW + npl - 1) / npl;
+      if (nvec > 8) continue;
+      const long wgs = (long)a.B * (C / sc);
+      if (best == 0 || wgs >= 256) { best = sc; bo = noct; bp = npl; bv = nvec; }
+      if (wgs < 256) break;
+    }
+    if (best > 0) {
+      const int threads = max(64, ((bo * bp + 63) / 64) * 64);
+      const size_t lds = (size_t)bo * bp * 64 + (size_t)8 * best * sizeof(float);
+      const dim3 g((unsigned)a.B, (unsigned)(C / best));
+      static bool attr_done[3][16] = {};
+      auto go = [&](auto kernel, int slot) {
+        ensure_lds_ceiling((const void*)kernel, attr_done[slot]);
+        hipLaunchKernelGGL(kernel, g, dim3(threads), lds, st, a, best, bo, bp);
+      };
+      if (bv <= 2) go(k_gn_bwd_onepass<2>, 0);
+      else if (bv <= 4) go(k_gn_bwd_onepass<4>, 1);
+      else go(k_gn_bwd_onepass<8>, 2);
+      return finish_launch("k_gn_bwd_onepass");
+    }
+  }
   const int vpp = C / 8, lanes = 256 / vpp;
   // ~8 pixels per thread and pass: slices of 8 * lanes pixels, at most ~1024 workgroups
   const int gx = max(1, min((a.HW + 8 * lanes - 1) / (8 * lanes), max(1, 1024 / max(a.B, 1))));
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gn_bwd_sums, dim3(gx, a.B), dim3(256), (size_t)(8 * C + 256 * 16) * sizeof(float), st, a);
   if (int rc = finish_launch("k_gn_bwd_sums")) return rc;
   hipLaunchKernelGGL(k_gn_bwd_dx, dim3(gx, a.B), dim3(256), (size_t)(8 * C + 4 * C) * sizeof(float), st, a);
