@@ -129,17 +129,34 @@ def network_roofline(model, batch, sampler=None):
     eng = getattr(model, "_engine", None)
     if eng is None:
         return None
-    plans = []
-    want_lb = None
-    if sampler is not None:                                          # the plans the sampler loop replays (bf16 or fp32 logits)
-        with sampler._borrow(model):
-            want_lb = bool(getattr(model, "_engine_logits_bf16", False))
-    for key, st in eng._plans.items():
-        if key[0] != batch or (want_lb is not None and key[-1] != want_lb):
-            continue
-        plans.extend(st[1] if isinstance(st, tuple) else [st])       # (logits, sub-plans, streams) when the batch runs as sub-batches
-    if not plans:
+    # the forward exactly as the sampler loop issues it: int32 states, the plan's own output buffer, and (when the sampler
+    # precomputes its grid's time projections) a time-projection row instead of the time path
+    from lib.models.models import borrow_engine_output
+    dev = next(model.parameters()).device
+    x = torch.randint(0, S, (batch, D), device=dev, dtype=torch.int32)
+    t = torch.full((batch,), 0.5, device=dev)
+    use_row = sampler is not None and getattr(sampler.cfg.sampler, "time_table", True) and hasattr(model, "engine_time_table")
+    row = model.engine_time_table(t[:1])[0] if use_row else None
+
+    def forward():
+        with (sampler._borrow(model) if sampler is not None else borrow_engine_output(model)):
+            model._engine_time_row = row
+            try:
+                return model(x, t)
+            finally:
+                model._engine_time_row = None
+
+    before = set(eng._plans.keys())
+    forward()
+    torch.cuda.synchronize()
+    lb = bool(forward().dtype == torch.bfloat16)
+    cand = [k for k in eng._plans if k[0] == batch and k[1] == torch.int32 and k[-1] == lb and (("row" in k) == bool(use_row)) and "slot" not in k]
+    new_keys = [k for k in cand if k not in before]
+    key = (new_keys or cand or [None])[0]
+    if key is None:
         return None
+    st = eng._plans[key]
+    plans = list(st[1]) if isinstance(st, tuple) else [st]       # (logits, sub-plans, streams) when the batch runs as sub-batches
     flops, secs, n = 0, 0.0, 0
     for st in plans:
         eng._run_plan(st)
@@ -159,17 +176,13 @@ def network_roofline(model, batch, sampler=None):
             n += 1
     seq = flops / secs / 1e12
     # the forward as it runs in the timed loop (HIP-graph replay, sub-batches on parallel streams, all kernels of the network)
-    x = torch.randint(0, S, (batch, D), device=next(model.parameters()).device)
-    t = torch.full((batch,), 0.5, device=x.device)
-    from lib.models.models import borrow_engine_output
-    with (sampler._borrow(model) if sampler is not None else borrow_engine_output(model)):   # as the sampler loop calls it: the plan's own output buffer, no copy
-        model(x, t)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            model(x, t)
-        e1.record()
-        e1.synchronize()
+    forward()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        forward()
+    e1.record()
+    e1.synchronize()
     fwd = e0.elapsed_time(e1) * 1e-3 / 10
     ach = flops / fwd / 1e12
     return {"kernel": "score-network forward: ctdd k_conv_ring / k_conv_patch / k_conv_igemm bf16 implicit-GEMM convolutions (+ GroupNorm, attention, time MLP)",
