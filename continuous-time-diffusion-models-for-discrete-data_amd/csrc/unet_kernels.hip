@@ -580,8 +580,16 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
 // together with its slab -- one barrier pair and one round of global loads per chunk instead of one per tap.  With a
 // [32][BK] weight tile per tap the per-tap version spent a global-load latency (~1.5k cycles) on every 4 matrix
 // instructions: a 7x7 convolution of 128 samples ran at 6 % of the matrix pipe.
-template <int BK, int BNT, int WM, bool EXT = false, bool ALLTAPS = false>
+// DIRECT (bf16 output, no statistics, no logits layout, no split-K -- the small levels of the inference plans since their
+// GroupNorm computes its own statistics): the matrix instruction's operands are swapped, C^T = W . X^T, so that a lane holds ONE
+// PIXEL's 4-channel pieces (channels 8q + 4g + 0..3 of each 32-channel tile) instead of one channel's 16 pixels.  Bias and
+// time bias are the accumulators' initial values, the residual is added as 8-byte pieces in that layout, two
+// v_permlane32_swap per 16 channels give each lane 8 consecutive channels, and the row leaves as 16-byte stores straight from
+// the registers: no LDS image, no barrier, ~2 instructions per output instead of ~8 (the row-major epilogue was 8 k of a 7x7
+// workgroup's 30 k cycles).
+template <int BK, int BNT, int WM, bool EXT = false, bool ALLTAPS = false, bool DIRECT = false>
 __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
+  static_assert(!(DIRECT && EXT), "direct epilogue: plain bf16 outputs only");
   constexpr int BN = 32 * BNT, BMP = 4 * WM, MT = WM / 32;
   constexpr int LDK = BK + 8, VPR = BK / 8;
   constexpr int BV = (BN * VPR + 255) / 256;
@@ -700,6 +708,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
     for (int t = 0; t < BNT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][t][i] = 0.0f;
+  if constexpr (DIRECT) {                                        // register r of tile (mt, t): channel n0 + 32 t + 8 (r >> 2) + 4 g + (r & 3)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int64_t p = p0 + wave * WM + mt * 32 + li;
+      const int bsm = (int)((p < M ? p : M - 1) / HW);
+#pragma unroll
+      for (int t = 0; t < BNT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + 32 * t + 8 * q + 4 * g;
+          if (n < a.N) {
+            float4 v = a.bias ? *(const float4*)(a.bias + n) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (a.tbias) {
+              const float4 tv = *(const float4*)(a.tbias + (size_t)bsm * a.tb_stride + n);
+              v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
+            }
+            acc[mt][t][4 * q] = v.x; acc[mt][t][4 * q + 1] = v.y; acc[mt][t][4 * q + 2] = v.z; acc[mt][t][4 * q + 3] = v.w;
+          }
+        }
+    }
+  }
 
   int u = zs;
   int sgi, c0, kbase;
@@ -752,7 +781,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
         for (int ks = 0; ks < KS; ++ks) fetch(0, ks, ks);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks]), __builtin_bit_cast(bf16x8, fb[ks]), acc[0][0], 0, 0, 0);
+          acc[0][0] = DIRECT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[ks]), __builtin_bit_cast(bf16x8, fa[ks]), acc[0][0], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[ks]), __builtin_bit_cast(bf16x8, fb[ks]), acc[0][0], 0, 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) fetch(i / KS, i % KS, i);
@@ -760,7 +790,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
         for (int i = 0; i < 9 * KS; ++i) {
           const bf16x8 af_ = __builtin_bit_cast(bf16x8, fa[i % DEPTH]), bf_ = __builtin_bit_cast(bf16x8, fb[i % DEPTH]);
           if (i + DEPTH < 9 * KS) fetch((i + DEPTH) / KS, (i + DEPTH) % KS, i % DEPTH);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_, bf_, acc[0][0], 0, 0, 0);
+          acc[0][0] = DIRECT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf_, af_, acc[0][0], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_, bf_, acc[0][0], 0, 0, 0);
         }
       }
     } else
@@ -794,7 +825,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
           const bf16x8 bf = *(const bf16x8*)(Bw + (size_t)t * 32 * LDK + ks * 16);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf, acc[mt][t], 0, 0, 0);
+            acc[mt][t] = DIRECT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[mt], acc[mt][t], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf, acc[mt][t], 0, 0, 0);
         }
       }
       if (!ALLTAPS && tap + 1 < ntap) {
@@ -807,12 +839,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_patch(const ConvArgs a) {
   }
 
   PSTAMP()
+  if constexpr (DIRECT) {
+    unsigned short* const outp = a.out_hi;
+    const unsigned short* const resp = a.res_bf16;
+    const int aN = a.N;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int64_t p = p0 + wave * WM + mt * 32 + li;
+      const bool prow = p < M;
+      const size_t rowoff = (size_t)(prow ? p : 0) * aN;
+      uint2 rr[BNT][4];
+      if (resp) {
+#pragma unroll
+        for (int t = 0; t < BNT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + 32 * t + 8 * q + 4 * g;
+            rr[t][q] = (prow && n < aN) ? *(const uint2*)(resp + rowoff + n) : make_uint2(0u, 0u);
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < BNT; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          unsigned w[2][2];                                      // [piece q = 2h, 2h + 1][two packed pairs]
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int q = 2 * h + e;
+            float v0 = acc[mt][t][4 * q], v1 = acc[mt][t][4 * q + 1], v2 = acc[mt][t][4 * q + 2], v3 = acc[mt][t][4 * q + 3];
+            if (resp) {
+              v0 += __uint_as_float(rr[t][q].x << 16); v1 += __uint_as_float(rr[t][q].x & 0xFFFF0000u);
+              v2 += __uint_as_float(rr[t][q].y << 16); v3 += __uint_as_float(rr[t][q].y & 0xFFFF0000u);
+            }
+            w[e][0] = pack2_bf16(v0, v1); w[e][1] = pack2_bf16(v2, v3);
+          }
+          // lower lane of the pair: (its piece 2h, the upper lane's piece 2h) = channels 16h + 0..7; upper lane: the two pieces
+          // 2h + 1 = channels 16h + 8..15
+          const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+          const int n = n0 + 32 * t + 16 * h + 8 * g;
+          if (prow && n < aN) *(uint4*)(outp + rowoff + n) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    }
+  } else {
   const TileStats ts = tile_stats_begin(a, smem, p0, BMP, n0, BN, M, HW);     // (barrier: the LDS tiles are out of use)
   if (!ts.lds) __syncthreads();
   float* xt = (float*)(smem + (size_t)tile_stats_samples(BMP, HW) * BN * 16) + (size_t)wave * 32 * (BN + 4);
   conv_epilogue_rows<BNT, MT, EXT>(a, acc, xt, p0 + wave * WM, n0, M, HW, ts);
   PSTAMP()
   tile_stats_flush(a, ts);
+  }
   PSTAMP()
 #ifdef CTDD_PATCH_STAMPS
   if (lane == 0 && a.acc_buf) {
@@ -1999,7 +2075,7 @@ extern "C" int ctdd_unet_conv(const void* args_, int bk, int bnt, int f32, void*
   CTDD_REQUIRE(false, CTDD_ERANGE, "no conv instantiation for BK=%d BNT=%d", bk, bnt);
 }
 
-template <int BK, int BNT, int WM, bool EXT = false, bool ALLTAPS = false>
+template <int BK, int BNT, int WM, bool EXT = false, bool ALLTAPS = false, bool DIRECT = false>
 static int launch_patch(const ConvArgs& a, hipStream_t st) {
   constexpr int LDK = BK + 8;
   const int PR = 4 * WM + 2 * (a.W + 1);
@@ -2009,8 +2085,8 @@ static int launch_patch(const ConvArgs& a, hipStream_t st) {
   const int64_t M = (int64_t)a.B * a.H * a.W;
   dim3 g((unsigned)((M + 4 * WM - 1) / (4 * WM)), (unsigned)((a.N + 32 * BNT - 1) / (32 * BNT)), a.ksplit > 1 ? a.ksplit : 1);
   static bool attr_done[16] = {};
-  ensure_lds_ceiling((const void*)k_conv_patch<BK, BNT, WM, EXT, ALLTAPS>, attr_done);
-  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM, EXT, ALLTAPS>), g, dim3(256), lds, st, a);
+  ensure_lds_ceiling((const void*)k_conv_patch<BK, BNT, WM, EXT, ALLTAPS, DIRECT>, attr_done);
+  hipLaunchKernelGGL((k_conv_patch<BK, BNT, WM, EXT, ALLTAPS, DIRECT>), g, dim3(256), lds, st, a);
   if (int rc = finish_launch("k_conv_patch")) return rc;
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(k_conv_finish, dim3((a.N + 31) / 32, a.B), dim3(256), 0, st, a);
@@ -2038,6 +2114,16 @@ extern "C" int ctdd_unet_conv_patch(const void* args_, int bk, int bnt, int wm, 
     CASEX(64, 4) CASEX(64, 2) CASEX(64, 1) CASEX(48, 4) CASEX(48, 3) CASEX(48, 2) CASEX(48, 1) CASEX(32, 4) CASEX(32, 3) CASEX(32, 1) CASEX(16, 1)
 #undef CASEX
     CTDD_REQUIRE(false, CTDD_ERANGE, "no patch-conv instantiation with activation / split output for BK=%d BNT=%d WM=%d (wm must be 32)", bk, bnt, wm);
+  }
+  // bf16 output without statistics / logits layout / split-K / fp32 copies: the direct (transposed-accumulator) epilogue
+  static const bool no_direct = [] { const char* e = getenv("CTDD_CONV_NO_DIRECT"); return e && e[0] == '1'; }();
+  const bool direct = !no_direct && !a.stats && a.logits_C <= 0 && a.ksplit <= 1 && a.out_hi && !a.out_f32 && !a.res_f32 &&
+                      (!a.bias || ((uintptr_t)a.bias & 15) == 0) && (!a.tbias || (((uintptr_t)a.tbias & 15) == 0 && a.tb_stride % 4 == 0));
+  if (direct) {
+    if (bnt == 1 && wm == 32 && bk == 64) return launch_patch<64, 1, 32, false, true, true>(a, st);
+    if (bnt == 1 && wm == 32 && bk == 48) return launch_patch<48, 1, 32, false, true, true>(a, st);
+    if (bnt == 3 && wm == 64 && bk == 48) return launch_patch<48, 3, 64, false, false, true>(a, st);
+    if (bnt == 3 && wm == 32 && bk == 48) return launch_patch<48, 3, 32, false, false, true>(a, st);
   }
   if (bnt == 1 && wm == 32 && a.ksplit <= 1) {  // 32-column tiles (the small levels): every tap's weight tile staged per chunk
     if (bk == 64) return launch_patch<64, 1, 32, false, true>(a, st);
