@@ -443,47 +443,60 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
     }
   }
 
-  uint4 ra[AV], rb[BV];
-  auto load_chunk = [&](const ChunkIter<BK>& it) {
+  // Chunks in flight in registers: one.  (Two or three sets for the 32-column tiles of the tiny grids were measured, -DCTDD_IGEMM_DP:
+  // 39.6 / 40.5 / 42.2 us for the 7x7 stride-2 convolution of 128 samples -- the compiler's wait in front of the loop's first store
+  // falls back to vmcnt(0), so the extra sets only cost registers.  What did pay is below: branch-free staging loads.)
+#ifndef CTDD_IGEMM_DP
+#define CTDD_IGEMM_DP 1
+#endif
+  constexpr int DP = (BNT == 1 && !F32) ? CTDD_IGEMM_DP : 1;
+  uint4 rra[DP][AV], rrb[DP][BV];
+  unsigned rok[DP];
+  auto load_chunk = [&](const ChunkIter<BK>& it, uint4 (&ra)[AV], uint4 (&rb)[BV]) {
     const ConvSeg sg = a.seg[it.seg];
     const int kind = sg.kind;
     const unsigned char* src = F32 ? (const unsigned char*)sg.f32 : (const unsigned char*)sg.hi;
     const unsigned char* wsrc = F32 ? (const unsigned char*)a.w_f32 : (const unsigned char*)a.w_hi;
     int dy = 0, dx = 0;
     if (kind != SEG_1x1) { dy = it.tap / 3; dx = it.tap % 3; }
+    // Branch-free per vector: the segment kind only selects multipliers / offsets (wave-uniform scalars), validity is a bit
+    // product, the address is clamped and the load unconditional -- written as `ok ? load : 0` under a switch on the kind the
+    // compiler made every one of a chunk's vectors its own branch + load + wait (eight exposed latencies per chunk: the
+    // stride-2 convolutions of the sampler's plans went 55.8 -> 39.6 and 37.8 -> 31.0 us per 128 samples with this form).
+    const bool s2 = kind == SEG_3x3_S2, s2t = kind == SEG_3x3_S2T, up = kind == SEG_3x3_UP, one = kind == SEG_1x1;
+    const int mul = s2 ? 2 : 1;                                        // input coordinate = mul * output + add (before the halving of S2T / UP)
+    const int ady = one ? 0 : s2 ? dy : s2t ? -dy : dy - 1, adx = one ? 0 : s2 ? dx : s2t ? -dx : dx - 1;
+    const int hin = one ? a.H : a.Hin, win = one ? a.W : a.Win;
+    const int hlim = up ? a.H : hin, wlim = up ? a.W : win;            // bound of (yy, xx) before the halving
+    const int sh = (s2t || up) ? 1 : 0;
+    size_t offs[AV];
+    bool oks[AV];
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int v = tid + 256 * i;
       const int cv = v % VPR;
-      int yy, xx;
-      bool ok = pb[i] >= 0;
-      if (kind == SEG_3x3) { yy = py[i] + dy - 1; xx = px[i] + dx - 1; }
-      else if (kind == SEG_1x1) { yy = py[i]; xx = px[i]; }
-      else if (kind == SEG_3x3_S2) { yy = 2 * py[i] + dy; xx = 2 * px[i] + dx; }       // pad right/bottom only
-      else if (kind == SEG_3x3_S2T) { yy = py[i] - dy; xx = px[i] - dx; }              // transpose of the stride-2 conv: 2 oy + dy = y
-      else { yy = py[i] + dy - 1; xx = px[i] + dx - 1; }                               // on the upsampled grid
-      if (kind == SEG_3x3_S2T) {
-        ok = ok && yy >= 0 && xx >= 0 && !((yy | xx) & 1);
-        yy >>= 1; xx >>= 1;
-        ok = ok && yy < a.Hin && xx < a.Win;
-      } else if (kind == SEG_3x3_UP) {
-        ok = ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-        yy >>= 1; xx >>= 1;
-      } else if (kind == SEG_3x3_S2 || kind == SEG_3x3) {
-        ok = ok && yy >= 0 && yy < a.Hin && xx >= 0 && xx < a.Win;
-      }
-      const int hin = kind == SEG_1x1 ? a.H : a.Hin, win = kind == SEG_1x1 ? a.W : a.Win;
-      const size_t off = (((size_t)pb[i] * hin + yy) * win + xx) * sg.C + it.c0 + cv * EPV;
-      ra[i] = ok ? *(const uint4*)(src + off * ESZ) : make_uint4(0, 0, 0, 0);
+      const int yy = mul * py[i] + ady, xx = mul * px[i] + adx;
+      bool ok = (pb[i] >= 0) & (yy >= 0) & (xx >= 0) & (yy < (s2t ? 2 * hin : hlim)) & (xx < (s2t ? 2 * win : wlim));
+      ok = ok & !(s2t & (((yy | xx) & 1) != 0));                      // transpose of the stride-2 conv: only even coordinates hit an input
+      const int yh = yy >> sh, xh = xx >> sh;
+      oks[i] = ok;
+      offs[i] = ok ? (((size_t)pb[i] * hin + yh) * win + xh) * sg.C + it.c0 + cv * EPV : 0;
     }
+#pragma unroll
+    for (int i = 0; i < AV; ++i) ra[i] = *(const uint4*)(src + offs[i] * ESZ);
+    unsigned okm = 0;                                                  // validity bits: applied when the vectors go to LDS (store_chunk), not
+#pragma unroll                                                         // here -- a select on the loaded value would wait for it now
+    for (int i = 0; i < AV; ++i) okm |= (oks[i] ? 1u : 0u) << i;
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
       const int v = tid + 256 * i;
       const int n = v / VPR, cv = v % VPR;
-      const bool ok = v < BN * VPR && n0 + n < a.N;
-      const size_t off = (size_t)(n0 + n) * a.Ktot + it.koff + cv * EPV;
-      rb[i] = ok ? *(const uint4*)(wsrc + off * ESZ) : make_uint4(0, 0, 0, 0);
+      const bool ok = (v < BN * VPR) & (n0 + n < a.N);
+      const size_t off = ok ? (size_t)(n0 + n) * a.Ktot + it.koff + cv * EPV : 0;
+      rb[i] = *(const uint4*)(wsrc + off * ESZ);
+      okm |= (ok ? 1u : 0u) << (AV + i);
     }
+    return okm;
   };
   // fp32 tiles are stored with even k in the first half of the row and odd k in the second, so
   // that the 32x32x2 operand of lane (i, h) -- k = 2s + h -- is four consecutive floats per ds_read_b128
@@ -496,16 +509,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
       *(uint4*)(base + ((size_t)row * LDK + cv * 8) * 2) = v;
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](const uint4 (&ra)[AV], const uint4 (&rb)[BV], unsigned okm) {
+    auto masked = [](uint4 v, bool ok) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); };
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int v = tid + 256 * i;
-      put(As, v / VPR, v % VPR, ra[i]);
+      put(As, v / VPR, v % VPR, masked(ra[i], (okm >> i) & 1u));
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
       const int v = tid + 256 * i;
-      if (v < BN * VPR) put(Bs, v / VPR, v % VPR, rb[i]);
+      if (v < BN * VPR) put(Bs, v / VPR, v % VPR, masked(rb[i], (okm >> (AV + i)) & 1u));
     }
   };
 
@@ -518,16 +532,23 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
   const int nchunk = a.Ktot / BK;
   ChunkIter<BK> it;
   it.init();
-  load_chunk(it);
+#pragma unroll
+  for (int j = 0; j < DP; ++j)
+  {                                     // (loads are unconditional -- a set past the end re-reads the last chunk and is never stored --
+    rok[j] = load_chunk(it, rra[j], rrb[j]);          //  so that every path has the same number of loads in flight: with a conditional
+    if (j + 1 < nchunk) it.next(a);                   //  refill the compiler's wait before the next store fell back to vmcnt(0))
+  }
   const int li = lane & 31, g = lane >> 5;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c0_ = 0; c0_ < nchunk; c0_ += DP) {
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    const int c = c0_ + j;
+    if (c >= nchunk) break;
     __syncthreads();                    // everyone finished reading the previous chunk from LDS
-    store_chunk();
+    store_chunk(rra[j], rrb[j], rok[j]);
     __syncthreads();
-    if (c + 1 < nchunk) {               // prefetch the next chunk into registers behind the MFMAs
-      it.next(a);
-      load_chunk(it);
-    }
+    rok[j] = load_chunk(it, rra[j], rrb[j]);          // refill this register set: chunk c + DP, in flight behind the next DP chunks' MFMAs
+    if (c + DP + 1 < nchunk) it.next(a);
     if constexpr (F32) {
       const float* Aw = (const float*)As + (size_t)(wave * 32 + li) * LDK + g * (BK / 2);
       const float* Bw = (const float*)Bs + (size_t)li * LDK + g * (BK / 2);
@@ -556,6 +577,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const ConvArgs a) {
         }
       }
     }
+  }
   }
 
   // ---- epilogue.  lane: column n = n0 + 32 t + li ; register r: row 32*wave + (r&3) + 8*(r>>2) + 4*g
