@@ -95,6 +95,73 @@ __device__ inline bf16x8 frag_tr(const unsigned char* base, int p0, int tile, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// Matrix loop of one chunk (bf16): `nsteps` 16-position steps of NT + 1 transposed fragments and NT matrix instructions.
+// The wave arrangement is a template parameter so that the LDS bytes per step are constants: the loop runs the steps in
+// PAIRS from one set of running addresses -- the odd step's reads carry the step stride in the instruction's offset field --
+// with two fragment sets (even / odd steps) that are each re-loaded where their previous contents were last used, so nothing
+// is copied between registers.  (The first version rotated `next -> current` fragment registers and re-added the step
+// offset per read: 40 register copies and 40 address adds per step, 17 vector instructions per matrix instruction;
+// rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA.)  The taps go in groups of three: matrix instructions of group g, then the
+// NEXT step's reads of group g -- at every wait the reads that may stay in flight number 12 or 14, which the 4-bit LDS
+// counter can express (all twenty reads of a step issued in one block put 20 younger reads behind the ones a wait is for:
+// the counter saturates and the wave waits for six reads it does not need yet, behind the other three waves' queues --
+// measured 1.32 -> 1.80 ms for the 3x3 table of the MNIST step).
+template <int NT, int NWN>
+__device__ __attribute__((always_inline)) inline void wgrad_steps(const unsigned (&la)[2], const unsigned (&lb)[NT][2], int nsteps,
+                                                                   f32x16 (&acc)[NT]) {
+  constexpr unsigned STY = 16u * NWN * 64u, STX = 16u * (4 / NWN) * 64u;     // LDS bytes per 16-position step (dY / X tile)
+  constexpr int GS = NT == 9 ? 3 : NT, NG = NT / GS;
+  typedef __attribute__((address_space(3))) s16x4* lptr;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto rd = [](unsigned addr0, unsigned addr1, unsigned imm) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uintptr_t)(addr0 + imm));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uintptr_t)(addr1 + imm));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  unsigned y0 = la[0], y1 = la[1], x0[NT], x1[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { x0[t] = lb[t][0]; x1[t] = lb[t][1]; }
+  bf16x8 a0 = rd(y0, y1, 0), b0[NT], a1 = a0, b1[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { b0[t] = rd(x0[t], x1[t], 0); b1[t] = b0[t]; }
+  int s = 0;
+  for (; s + 2 <= nsteps; s += 2) {
+    // even step on set 0; set 1 <- step s + 1
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = gq * GS; t < (gq + 1) * GS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gq == 0) a1 = rd(y0, y1, STY);
+#pragma unroll
+      for (int t = gq * GS; t < (gq + 1) * GS; ++t) b1[t] = rd(x0[t], x1[t], STX);
+    }
+    // odd step on set 1; set 0 <- step s + 2 (or, behind the last pair, the same positions again: not used)
+    const bool more = s + 2 < nsteps;
+    const unsigned iy = more ? 2 * STY : 0u, ix = more ? 2 * STX : 0u;
+    y0 += iy; y1 += iy;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { x0[t] += ix; x1[t] += ix; }
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = gq * GS; t < (gq + 1) * GS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gq == 0) a0 = rd(y0, y1, 0);
+#pragma unroll
+      for (int t = gq * GS; t < (gq + 1) * GS; ++t) b0[t] = rd(x0[t], x1[t], 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (s < nsteps) {                                          // odd step count: the last step sits in set 0
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[t], acc[t], 0, 0, 0);
+  }
+}
+
 // One launch computes the weight gradients of MANY convolutions (table of WgradArgs, blockIdx.z = table entry): the
 // backward plan defers every weight gradient to its end (operands stay alive), so a level's seven equal-shaped
 // convolutions fill the chip together and each needs only a few M-split workgroups.  That matters because the M-split
@@ -274,30 +341,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
       }
     } else {
-      typedef __attribute__((address_space(3))) s16x4* lptr;
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      auto rd = [&](unsigned addr0, unsigned addr1) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uintptr_t)addr0);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(uintptr_t)addr1);
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
-      };
-      bf16x8 af = rd(la[0], la[1]), bfr[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bfr[t] = rd(lb[t][0], lb[t][1]);
-      for (int p0 = 0; p0 < KP; p0 += 16) {
-        const bool more = p0 + 16 < KP;
-        const unsigned sy = (unsigned)(p0 + 16) * rowLY, sx = (unsigned)(p0 + 16) * rowLX;
-        bf16x8 an = af, bn[NT];
-        if (more) an = rd(la[0] + sy, la[1] + sy);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bn[t] = more ? rd(lb[t][0] + sx, lb[t][1] + sx) : bfr[t];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[t], acc[t], 0, 0, 0);
-        af = an;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bfr[t] = bn[t];
-      }
+      const int nsteps = KP >> 4;
+      if (nwn == 2) wgrad_steps<NT, 2>(la, lb, nsteps, acc);
+      else if (nwn == 4) wgrad_steps<NT, 4>(la, lb, nsteps, acc);
+      else wgrad_steps<NT, 1>(la, lb, nsteps, acc);
     }
   }
   if (!active) return;

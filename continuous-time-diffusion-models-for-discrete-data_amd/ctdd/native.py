@@ -24,7 +24,8 @@ class CtddError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libctdd.so")
+    """libctdd.so next to the package; CTDD_LIBRARY names another build of it (A/B measurements of one kernel change)."""
+    return os.environ.get("CTDD_LIBRARY") or os.path.join(_HERE, "libctdd.so")
 
 
 _P, _I, _F, _U64, _U32, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_int64
