@@ -214,13 +214,21 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
   const int vn = 32 * nwn / EPV, vc = 32 * nwc / EPV;                      // 16-byte vectors per staged row
-  const __attribute__((address_space(1))) unsigned char* xg = (const __attribute__((address_space(1))) unsigned char*)a.x;
-  const __attribute__((address_space(1))) unsigned char* yg = (const __attribute__((address_space(1))) unsigned char*)a.dy;
   const int HW = a.H * a.W;
   const float inv_H1 = 1.0f / (float)(a.H + 1);
   const unsigned rowY = (unsigned)a.ldy * ESZ, rowX = (unsigned)a.C * ESZ; // bytes per pixel
-  // ---- slot tables (chunk-invariant): LDS byte offset | row << 20, byte offset inside the image row, -1 = unused slot
-  int yl[SY], yc[SY], xl[SX], xc_[SX];
+  // Operands through buffer descriptors (32-bit byte offsets; the host keeps both tensors below 2 GiB): an out-of-range
+  // offset reads zeros, which is how rows beyond the batch, the zero rows of the extended row list, a stride-2 tap outside
+  // the (padded) input and unused staging slots become zero vectors -- no select per vector at the LDS write.
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned ybytes = (unsigned)a.B * (unsigned)HW * rowY, xbytes = (unsigned)a.B * (unsigned)(a.Hin * a.Win) * rowX;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, xbytes, 0x00020000);
+  // ---- slot tables (chunk-invariant): LDS byte offset (unused slots write a 16-byte pad behind the tiles), row of the
+  // extended list, byte offset inside the image row (OOB = unused slot)
+  const int padY = (KP * nwn + XP * nwc) * TB, padX = padY - KP * nwn * TB;
+  int yl[SY], yr[SY], xl[SX], xr[SX];
+  unsigned yc[SY], xc_[SX];
   const int nY = three ? a.nlr * a.W * vn : KP * vn, nX = three ? (a.nlr + 2) * a.W * vc : KP * vc;
 #pragma unroll
   for (int u = 0; u < SY; ++u) {
@@ -228,8 +236,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
     const int cv = v % vn, pi = v / vn, lr = three ? pi / a.W : 0, xx = three ? pi - lr * a.W : pi;
     const int ch = n_base + cv * EPV;
     const int pos = three ? lr * Wp + xx + 1 : pi;
-    yl[u] = (v < nY && ch < a.ldy) ? (lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwn) | (lr << 20)) : -1;
-    yc[u] = (int)((unsigned)xx * rowY + (unsigned)ch * ESZ);
+    const bool used = v < nY && ch < a.ldy;
+    yl[u] = used ? lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwn) : padY;
+    yr[u] = lr;
+    yc[u] = used ? (unsigned)xx * rowY + (unsigned)ch * ESZ : OOB;
   }
 #pragma unroll
   for (int u = 0; u < SX; ++u) {
@@ -237,13 +247,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
     const int cv = v % vc, pi = v / vc, lr = three ? pi / a.W : 0, xx = three ? pi - lr * a.W : pi;
     const int ch = c_base + cv * EPV;
     const int pos = three ? lr * Wp + xx + 2 : pi;
-    xl[u] = (v < nX && ch < a.C) ? (lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwc) | (lr << 20)) : -1;
-    xc_[u] = (int)((unsigned)xx * rowX + (unsigned)ch * ESZ);
+    const bool used = v < nX && ch < a.C;
+    xl[u] = used ? lds_off<F32>(pos, cv * EPV / 32, (cv * EPV % 32) * ESZ, nwc) : padX;
+    xr[u] = lr;
+    xc_[u] = used ? (unsigned)xx * rowX + (unsigned)ch * ESZ : OOB;
   }
   const int64_t M = (int64_t)a.B * HW;
   const int dyy = a.tap / 3, dxx = a.tap % 3;                              // stride-2 kind: this entry's tap
   // lane parts of the fragment read addresses (LDS byte addresses; bf16 path)
-  const unsigned rowLY = (unsigned)nwn * TB, rowLX = (unsigned)nwc * TB;   // LDS bytes per position
   unsigned la[2] = {0, 0}, lb[NT][2];
   {
     const int grp = lane >> 4, i16 = lane & 15, h = grp >> 1, cb = 16 * (grp & 1), q = i16 >> 2, pp = i16 & 3;
@@ -262,56 +273,60 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
   // Software pipeline (one workgroup per CU, one wave per SIMD): the next chunk's vectors are loaded into registers before
   // the matrix loop of the current one and written to LDS after it, so the global latency hides behind the MFMAs.
   u32x4 vy[SY], vx[SX];
-  unsigned oky = 0, okx = 0;                                               // per-slot "real data" bits (else a zero vector)
+  const bool plain = !three && a.kind == WG_1x1;
   auto load_chunk = [&](int chunk) {
-    oky = okx = 0;
     if (three) {
       // extended rows E0 .. E0 + nlr - 1 of the list (image b, row y) = (E / (H+1), E % (H+1)); y == H is the zero row
       const int E0 = chunk * a.nlr;
 #pragma unroll
       for (int u = 0; u < SY; ++u) {
-        const int E = E0 + (yl[u] >> 20);
+        const int E = E0 + yr[u];
         const int b = (int)(((float)E + 0.5f) * inv_H1), y = E - b * (a.H + 1);
-        const bool ok = yl[u] >= 0 && y < a.H && b < a.B;
-        oky |= (ok ? 1u : 0u) << u;
-        vy[u] = *(gptr16)(yg + (ok ? (unsigned)(b * HW + y * a.W) * rowY + (unsigned)yc[u] : 0u));
+        const bool ok = y < a.H && b < a.B;
+        vy[u] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? (unsigned)(b * HW + y * a.W) * rowY + yc[u] : OOB, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < SX; ++u) {
-        const int E = E0 - 1 + (xl[u] >> 20);
+        const int E = E0 - 1 + xr[u];
         const int b = E < 0 ? 0 : (int)(((float)E + 0.5f) * inv_H1), y = E < 0 ? a.H : E - b * (a.H + 1);
-        const bool ok = xl[u] >= 0 && y < a.H && b < a.B;
-        okx |= (ok ? 1u : 0u) << u;
-        vx[u] = *(gptr16)(xg + (ok ? (unsigned)(b * HW + y * a.W) * rowX + (unsigned)xc_[u] : 0u));
+        const bool ok = y < a.H && b < a.B;
+        vx[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? (unsigned)(b * HW + y * a.W) * rowX + xc_[u] : OOB, 0, 0);
       }
+    } else if (plain) {
+      // rows P0 .. P0 + KP - 1 of both operands: the descriptors are moved to the chunk (scalar work), the per-slot offsets
+      // are the chunk-invariant ones of the tables and rows beyond the last fall out of range by themselves
+      const unsigned P0 = (unsigned)chunk * (unsigned)KP;
+      const unsigned oy = P0 * rowY, ox = P0 * rowX;
+      const __amdgpu_buffer_rsrc_t yr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.dy + oy), 0, ybytes - oy, 0x00020000);
+      const __amdgpu_buffer_rsrc_t xr_ = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)a.x + ox), 0, xbytes - ox, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < SY; ++u) vy[u] = __builtin_amdgcn_raw_buffer_load_b128(yr_, yc[u], 0, 0);
+#pragma unroll
+      for (int u = 0; u < SX; ++u) vx[u] = __builtin_amdgcn_raw_buffer_load_b128(xr_, xc_[u], 0, 0);
     } else {
       // output pixels P0 .. P0 + KP - 1 in flattened (b, oy, ox) order; X gathered at the tap's input pixel
       const int64_t P0 = (int64_t)chunk * KP;
 #pragma unroll
       for (int u = 0; u < SY; ++u) {
         const int pi = (tid + 256 * u) / vn;
-        const bool ok = yl[u] >= 0 && P0 + pi < M;
-        oky |= (ok ? 1u : 0u) << u;
-        vy[u] = *(gptr16)(yg + (ok ? (size_t)(P0 + pi) * rowY + (unsigned)(yc[u] - pi * (int)rowY) : 0));
+        const bool ok = P0 + pi < M;
+        vy[u] = __builtin_amdgcn_raw_buffer_load_b128(yrs, ok && yc[u] != OOB ? (unsigned)P0 * rowY + yc[u] : OOB, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < SX; ++u) {
         const int pi = (tid + 256 * u) / vc;
         const int64_t p = P0 + pi;
-        size_t off = 0;
-        bool ok = xl[u] >= 0 && p < M;
-        if (ok) {
+        unsigned off = OOB;
+        if (p < M && xc_[u] != OOB) {
           if (a.kind == WG_3x3_S2) {
             const int b = (int)(p / HW), r = (int)(p - (int64_t)b * HW), oy = r / a.W, ox = r - oy * a.W;
             const int yy = 2 * oy + dyy, xx = 2 * ox + dxx;
-            ok = yy < a.Hin && xx < a.Win;
-            off = ok ? (size_t)(((size_t)b * a.Hin + yy) * a.Win + xx) * rowX + (unsigned)(xc_[u] - pi * (int)rowX) : 0;
+            if (yy < a.Hin && xx < a.Win) off = (unsigned)((b * a.Hin + yy) * a.Win + xx) * rowX + (xc_[u] - (unsigned)pi * rowX);
           } else {
-            off = (size_t)p * rowX + (unsigned)(xc_[u] - pi * (int)rowX);
+            off = (unsigned)p * rowX + (xc_[u] - (unsigned)pi * rowX);
           }
         }
-        okx |= (ok ? 1u : 0u) << u;
-        vx[u] = *(gptr16)(xg + off);
+        vx[u] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
       }
     }
   };
@@ -319,11 +334,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
   for (int chunk = blockIdx.x; chunk < a.nchunks; chunk += a.grid_x) {
     __syncthreads();                                                       // the previous chunk's fragments are read
 #pragma unroll
-    for (int u = 0; u < SY; ++u)
-      if (yl[u] >= 0) *(u32x4*)(Ys + (yl[u] & 0xFFFFF)) = (oky >> u) & 1u ? vy[u] : (u32x4)(0u);
+    for (int u = 0; u < SY; ++u) *(u32x4*)(Ys + yl[u]) = vy[u];
 #pragma unroll
-    for (int u = 0; u < SX; ++u)
-      if (xl[u] >= 0) *(u32x4*)(Xs + (xl[u] & 0xFFFFF)) = (okx >> u) & 1u ? vx[u] : (u32x4)(0u);
+    for (int u = 0; u < SX; ++u) *(u32x4*)(Xs + xl[u]) = vx[u];
     __syncthreads();
     if (chunk + a.grid_x < a.nchunks) load_chunk(chunk + a.grid_x);
     if (!active) continue;
@@ -1066,8 +1079,8 @@ extern "C" int ctdd_unet_wgrad(const void* table_dev, const void* table_host, in
     CTDD_REQUIRE((a.kind == WG_3x3) == nine, CTDD_EINVAL, "wgrad[%d]: a table holds nine-tap entries or one-tap entries, not both", i);
     CTDD_REQUIRE(a.nlr > 0 && a.nchunks > 0 && a.grid_x > 0 && a.tap >= 0 && a.tap < 9, CTDD_EINVAL, "wgrad[%d]: nlr=%d nchunks=%d grid=%d", i,
                  a.nlr, a.nchunks, a.grid_x);
-    CTDD_REQUIRE((size_t)a.B * a.Hin * a.Win * a.C * (f32 ? 4 : 2) < (1ull << 32) && (size_t)a.B * a.H * a.W * a.ldy * (f32 ? 4 : 2) < (1ull << 32),
-                 CTDD_ERANGE, "wgrad[%d]: operand beyond 32-bit byte offsets", i);
+    CTDD_REQUIRE((size_t)a.B * a.Hin * a.Win * a.C * (f32 ? 4 : 2) < (1ull << 31) && (size_t)a.B * a.H * a.W * a.ldy * (f32 ? 4 : 2) < (1ull << 31),
+                 CTDD_ERANGE, "wgrad[%d]: operand beyond 2 GiB (buffer offsets; 0x80000000 marks an absent vector)", i);
     const int nwc = 4 / a.nwn, Wp = a.W + 2, vn = 32 * a.nwn / epv, vc = 32 * nwc / epv;
     int KP, XP, nY, nX;
     if (a.kind == WG_3x3) {
@@ -1079,7 +1092,7 @@ extern "C" int ctdd_unet_wgrad(const void* table_dev, const void* table_host, in
       KP = XP = a.nlr; nY = KP * vn; nX = KP * vc;
     }
     CTDD_REQUIRE(nY <= 256 * 8 && nX <= 256 * 10, CTDD_ERANGE, "wgrad[%d]: chunk of %d + %d vectors exceeds the staging slots (8 + 10 per thread)", i, nY, nX);
-    const size_t l = ((size_t)KP * a.nwn + (size_t)XP * nwc) * tb;
+    const size_t l = ((size_t)KP * a.nwn + (size_t)XP * nwc) * tb + 16;     // (+ the pad unused staging slots write)
     CTDD_REQUIRE(l <= 160 * 1024 && l < (1u << 20), CTDD_ERANGE, "wgrad[%d]: %zu bytes of LDS", i, l);
     if (l > lds) lds = l;
     const int groups = ((a.N + 32 * a.nwn - 1) / (32 * a.nwn)) * ((a.C + 32 * nwc - 1) / (32 * nwc));
