@@ -182,7 +182,8 @@ def _wgrad_geometry(rows, N, K, bf16, budget=144 * 1024):
     raise native.CtddError("weight gradient: no chunk fits the kernel's staging slots")
 
 
-WGRAD_WORKGROUPS = 512          # M-split target per launch (two per CU: measured best over 256 / 512 / 768 / 1536 at 28800 rows)
+WGRAD_WORKGROUPS = 512          # M-split target per launch (two per CU: measured best over 256 / 512 / 768 / 1536 at 28800 rows;
+                                # half of it for the small products -- up to 384 x 128 --, whose flush atomics weigh more: 11.1 vs 12.9 us)
 
 
 COLSUM_REPLICAS = 16
@@ -215,7 +216,7 @@ def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias, bufs=None):
     a.nwn, a.nlr = _wgrad_geometry(rows, N, K, bf16)
     a.nchunks = -(-rows // a.nlr)
     groups = -(-N // (32 * a.nwn)) * -(-K // (32 * (4 // a.nwn)))
-    a.grid_x, a.tap = max(1, min(a.nchunks, -(-WGRAD_WORKGROUPS // groups))), 0
+    a.grid_x, a.tap = max(1, min(a.nchunks, -(-(WGRAD_WORKGROUPS if N * K > 384 * 128 else WGRAD_WORKGROUPS // 2) // groups))), 0
     tab = (unet_train._WgradArgs * 1)(a)
     _ck(lib().ctdd_unet_wgrad(_device_table(bytes(tab), dev).data_ptr(), C.addressof(tab), 1, 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
     return dw, (_colsum(dy_op, rows, N, ld, bf16, None if bufs is None else bufs[1]) if bias else None)

@@ -248,8 +248,8 @@ class TrainCtx:
         for a in ents:
             nwc = 4 // a.nwn
             KP = -(-(a.nlr * (a.W + 2)) // 16) * 16 if a.kind == WG_3x3 else a.nlr
-            # per chunk: (16-pixel steps x taps) matrix instructions per wave + a fixed staging / barrier share (~48 of them)
-            cost.append(a.nchunks * ((KP // 16) * (9 if a.kind == WG_3x3 else 1) + int(getattr(eng.cfg.model, "wgrad_chunk_overhead", 48))))
+            # per chunk: (16-pixel steps x taps) matrix instructions per wave + a fixed staging / barrier share (~24 of them since the buffer-load staging; swept 8 / 24 / 48)
+            cost.append(a.nchunks * ((KP // 16) * (9 if a.kind == WG_3x3 else 1) + int(getattr(eng.cfg.model, "wgrad_chunk_overhead", 24))))
             groups.append(-(-a.N // (32 * a.nwn)) * -(-a.C // (32 * nwc)))
         total = sum(c * g for c, g in zip(cost, groups))
         target = max(1, total // (256 * int(getattr(eng.cfg.model, "wgrad_wgs_per_cu", 2))))

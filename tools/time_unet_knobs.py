@@ -19,8 +19,6 @@ def run(**over):
     for _ in range(20): l = step.step(state, loss, mb); state["n_iter"] += 1
     torch.cuda.synchronize()
     print(over, "%.3f ms/step" % ((time.perf_counter() - t0) / 20 * 1e3), flush=True)
-for w in (2, 4):
-    for ov in (16, 96, 160):
+for w in (1, 2, 3, 4):
+    for ov in (8, 24, 48):
         run(wgrad_wgs_per_cu=w, wgrad_chunk_overhead=ov)
-run(wgrad_wgs_per_cu=2)
-run(wgrad_wgs_per_cu=3)
