@@ -1787,6 +1787,11 @@ __global__ __launch_bounds__(1024) void k_gn_onepass(const GnArgs a, int slabC, 
     double acc = 0.0;
     for (int q = 0; q < npl; ++q) acc += (double)pp[(size_t)q * noct * 16];
     red[r] = acc;
+    // training plans: the per-(sample, channel) sums also go to the sources' statistics buffers (what the producers'
+    // epilogues would have accumulated), for the GroupNorm backward
+    const int c = cs0 + cl;
+    if (c < a.C1) { if (a.st1) ((double*)a.st1)[((size_t)b * a.C1 + c) * 2 + m] = acc; }
+    else if (a.st2) ((double*)a.st2)[((size_t)b * a.C2 + (c - a.C1)) * 2 + m] = acc;
   }
   __syncthreads();
   for (int cl = t; cl < slabC; cl += blockDim.x) {

@@ -138,7 +138,9 @@ class _Tensor:
         self.B, self.H, self.W, self.C = B, H, W, Cn
         self.f32 = torch.empty((M, Cn), dtype=torch.float32, device=dev) if eng.precise else None
         self.hi = None if eng.precise else torch.empty((M, Cn), dtype=torch.bfloat16, device=dev)
-        self.stats = eng.alloc_stats(B * Cn * 2) if (stats and not H * W <= getattr(eng, "_plan_no_stats_hw", 0)) else None
+        small = H * W <= getattr(eng, "_plan_no_stats_hw", 0)      # a one-pass GroupNorm level: no statistics from the producers
+        self.stats_by_gn = bool(stats and small and getattr(eng, "_plan_gn_writes_stats", False))   # training: k_gn_onepass leaves them for backward
+        self.stats = eng.alloc_stats(B * Cn * 2) if (stats and (not small or self.stats_by_gn)) else None
         eng._live.append(self)           # raw pointers are baked into the plan: keep every buffer alive
 
 
@@ -199,7 +201,9 @@ class UNetEngine:
         # bf16 inference plans: GroupNorm as one pass per tensor with the statistics inside (k_gn_onepass), no statistics in
         # the convolution epilogues (cfg.model.gn_onepass, default on); a net with a GroupNorm the kernel does not cover is
         # rebuilt the old way (statistics by the producers, k_gn_apply)
-        if (not self.precise) and tc is None and int(getattr(self.cfg.model, "gn_onepass", 1)):
+        # (training plans too, cfg.model.gn_onepass_train: the kernel then also writes each source's per-channel sums into the
+        #  tensors' statistics buffers, which the GroupNorm backward reads)
+        if (not self.precise) and int(getattr(self.cfg.model, "gn_onepass", 1)) and (tc is None or int(getattr(self.cfg.model, "gn_onepass_train", 1))):
             try:
                 return self._build_impl(B, x_dtype, logits_out, tc, logits_bf16, uniform_t, onepass_gn=True)
             except _GnUncovered:
@@ -212,6 +216,7 @@ class UNetEngine:
         #  small workgroups of k_gn_apply, and those tensors keep their statistics epilogues.  MNIST net, batch 256, sampler loop:
         #  off 85.1 k sample-steps/s, 7x7 only 85.8 k, 7x7 + 14x14 87.9 k, all levels 85.1 k)
         self._plan_no_stats_hw = int(getattr(m, "gn_onepass_max_hw", 256)) if onepass_gn else 0
+        self._plan_gn_writes_stats = bool(onepass_gn and tc is not None)
         gn_threads = int(getattr(m, "gn_threads", 512))    # (measured in the two-chain sampler loop: 384-512 best, 1024 -1 %)
         lib = _lib()
         dev = self.dev
@@ -298,7 +303,7 @@ class UNetEngine:
                     a.out_f32 = ptr(out_f32_tensor)
             elif out is not None:
                 a.out_f32, a.out_hi = ptr(out.f32), ptr(out.hi)
-                if out.stats is not None:
+                if out.stats is not None and not out.stats_by_gn:
                     stats_views.append((a, out.stats))
             a.logits_C = logits_C
             keep.append(a)

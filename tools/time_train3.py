@@ -59,9 +59,10 @@ def run(tag, engine, precision="bf16", B=64, steps=10, detail=False, **over):
                 print("      %8.1f us %s %s" % (us, lab, ("%.0f TF" % (fl / us / 1e6)) if fl else ""))
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+_over = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[2:] if "=" in a}     # cfg.model knobs, e.g. gn_onepass_train=0
 if which in ("all", "torch"):
     run("torch autograd network      ", "torch")
 if which in ("all", "hip"):
-    run("HIP training plan, bf16     ", "hip", "bf16", detail=True)
+    run("HIP training plan, bf16     ", "hip", "bf16", detail=True, **_over)
 if which in ("all", "fp32"):
     run("HIP training plan, fp32     ", "hip", "fp32")

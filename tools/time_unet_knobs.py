@@ -19,6 +19,12 @@ def run(**over):
     for _ in range(20): l = step.step(state, loss, mb); state["n_iter"] += 1
     torch.cuda.synchronize()
     print(over, "%.3f ms/step" % ((time.perf_counter() - t0) / 20 * 1e3), flush=True)
-for w in (1, 2, 3, 4):
-    for ov in (8, 24, 48):
-        run(wgrad_wgs_per_cu=w, wgrad_chunk_overhead=ov)
+import sys
+if len(sys.argv) > 1:                                   # knob=value pairs, one run per argument (e.g. gn_onepass_train=0)
+    for arg in sys.argv[1:]:
+        k, v = arg.split("=")
+        run(**{k: int(v)})
+else:
+    for w in (1, 2, 3, 4):
+        for ov in (8, 24, 48):
+            run(wgrad_wgs_per_cu=w, wgrad_chunk_overhead=ov)
