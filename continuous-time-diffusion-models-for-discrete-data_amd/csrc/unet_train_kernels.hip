@@ -68,6 +68,7 @@ struct WgradArgs {
   int nchunks;       // chunks in all; grid_x workgroups share them
   int grid_x;        // M-split of this entry (<= the launch's grid.x)
   int tap;           // WG_3x3_S2: the tap this entry computes (nine entries per stride-2 convolution)
+  float* gb;         // [N] fp32 or null: += column sums of dy over all pixels (the bias gradient), float atomics
 };
 
 // LDS image of a [positions][32 * tiles channels] operand tile.  bf16: the 64-byte pieces (one 32-channel tile) of a
@@ -273,6 +274,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
   // Software pipeline (one workgroup per CU, one wave per SIMD): the next chunk's vectors are loaded into registers before
   // the matrix loop of the current one and written to LDS after it, so the global latency hides behind the MFMAs.
   u32x4 vy[SY], vx[SX];
+  // Bias gradient (a.gb): the column sums of dY ride on the staging of the workgroups of channel group 0 -- every dY vector
+  // passes through their registers exactly once, and a thread's vectors are always the same EPV columns (256 % vn == 0).
+  // (It was a second table entry against an all-ones input: a re-read of dY with its own M-split atomics per convolution.)
+  const bool do_bias = a.gb != nullptr && grp_c == 0;
+  float bsum[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) bsum[j] = 0.0f;
   const bool plain = !three && a.kind == WG_1x1;
   auto load_chunk = [&](int chunk) {
     if (three) {
@@ -338,6 +346,18 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
 #pragma unroll
     for (int u = 0; u < SX; ++u) *(u32x4*)(Xs + xl[u]) = vx[u];
     __syncthreads();
+    if (do_bias) {                                                         // (absent vectors are zeros)
+#pragma unroll
+      for (int u = 0; u < SY; ++u) {
+        if constexpr (F32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bsum[j] += __uint_as_float(vy[u][j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { bsum[2 * j] += bf_lo(vy[u][j]); bsum[2 * j + 1] += bf_hi(vy[u][j]); }
+        }
+      }
+    }
     if (chunk + a.grid_x < a.nchunks) load_chunk(chunk + a.grid_x);
     if (!active) continue;
     if constexpr (F32) {
@@ -358,6 +378,20 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradArgs* __restrict__ tab
       if (nwn == 2) wgrad_steps<NT, 2>(la, lb, nsteps, acc);
       else if (nwn == 4) wgrad_steps<NT, 4>(la, lb, nsteps, acc);
       else wgrad_steps<NT, 1>(la, lb, nsteps, acc);
+    }
+  }
+  if (do_bias) {                                                           // (block-uniform)
+    __syncthreads();
+    float* bs = (float*)smem;                                              // [256][EPV]
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) bs[tid * EPV + j] = bsum[j];
+    __syncthreads();
+    if (tid < 32 * nwn) {                                                  // one thread per staged dY column
+      const int cvq = tid / EPV, j = tid % EPV;
+      float sacc = 0.0f;
+      for (int k = cvq; k < 256; k += vn) sacc += bs[k * EPV + j];
+      const int n = n_base + tid;
+      if (n < a.N) __hip_atomic_fetch_add(a.gb + n, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (!active) return;

@@ -186,7 +186,8 @@ WGRAD_WORKGROUPS = 512          # M-split target per launch (two per CU: measure
                                 # half of it for the small products -- up to 384 x 128 --, whose flush atomics weigh more: 11.1 vs 12.9 us)
 
 
-COLSUM_REPLICAS = 16
+COLSUM_REPLICAS = 1             # rows of the zeroed bias-gradient scratch a block hands to _wgrad (the column sums ride on the
+                                # weight-gradient launch; _colsum's two-stage sum with 16 replicas remains for callers without one)
 
 
 def _colsum(dy_op, rows, N, ld, bf16, rep=None):
@@ -196,7 +197,7 @@ def _colsum(dy_op, rows, N, ld, bf16, rep=None):
     n8 = -(-N // 8) * 8
     nblk = int(max(1, min(512, rows // 32)))
     if rep is None:
-        rep = torch.zeros((COLSUM_REPLICAS, n8), dtype=torch.float32, device=dev)
+        rep = torch.zeros((16, n8), dtype=torch.float32, device=dev)
     out = torch.empty((n8,), dtype=torch.float32, device=dev)
     _ck(lib().ctdd_hollow_colsum(None if bf16 else dy_op.data_ptr(), dy_op.data_ptr() if bf16 else None, rows, n8, ld, rep.data_ptr(), nblk,
                                  rep.shape[0], _st()), "ctdd_hollow_colsum")
@@ -206,8 +207,9 @@ def _colsum(dy_op, rows, N, ld, bf16, rep=None):
 
 def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias, bufs=None):
     """dW[N][K] = dY^T X (tokens are the contraction index: ctdd_unet_wgrad, kind 1x1) and, with `bias`, db[N] = the column
-    sums of dY (_colsum; a second table entry against an all-ones input cost 12-30 us per launch: re-read of dY + its own M-split
-    atomics; the two-stage column sum reads dY once).  bufs: zeroed (dW, column-sum replicas (COLSUM_REPLICAS, N)) scratch."""
+    sums of dY from the same launch (ctdd_wgrad_args.gb: they ride on the staging of the channel-group-0 workgroups; a second
+    table entry against an all-ones input cost 12-30 us per launch, the separate two-stage column sum 8.7 us + a reduction).
+    bufs: zeroed (dW, (1, N) bias-gradient) scratch."""
     dev = dy_op.device
     dw = bufs[0] if bufs is not None else torch.zeros((N, K), dtype=torch.float32, device=dev)
     a = unet_train._WgradArgs()
@@ -217,9 +219,14 @@ def _wgrad(x_op, dy_op, rows, N, ld, K, bf16, bias, bufs=None):
     a.nchunks = -(-rows // a.nlr)
     groups = -(-N // (32 * a.nwn)) * -(-K // (32 * (4 // a.nwn)))
     a.grid_x, a.tap = max(1, min(a.nchunks, -(-(WGRAD_WORKGROUPS if N * K > 384 * 128 else WGRAD_WORKGROUPS // 2) // groups))), 0
+    db = None
+    if bias:                                       # column sums of dY on the staging of the same launch (ctdd_wgrad_args.gb)
+        rep = bufs[1] if bufs is not None and bufs[1] is not None else torch.zeros((1, -(-N // 8) * 8), dtype=torch.float32, device=dev)
+        db = rep.view(-1)[:N]
+        a.gb = db.data_ptr()
     tab = (unet_train._WgradArgs * 1)(a)
     _ck(lib().ctdd_unet_wgrad(_device_table(bytes(tab), dev).data_ptr(), C.addressof(tab), 1, 0 if bf16 else 1, _st()), "ctdd_unet_wgrad")
-    return dw, (_colsum(dy_op, rows, N, ld, bf16, None if bufs is None else bufs[1]) if bias else None)
+    return dw, db
 
 
 def _layernorm(x, y, gamma, beta, film, eps, want_f32=True, want_hi=False):

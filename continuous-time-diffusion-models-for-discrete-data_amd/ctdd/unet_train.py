@@ -30,7 +30,7 @@ _P, _I, _F, _I64, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
 
 class _WgradArgs(C.Structure):
     _fields_ = [("x", _P), ("dy", _P), ("gw", _P), ("B", _I), ("H", _I), ("W", _I), ("Hin", _I), ("Win", _I), ("N", _I), ("ldy", _I),
-                ("C", _I), ("Ktot", _I), ("koff", _I), ("kind", _I), ("nlr", _I), ("nwn", _I), ("nchunks", _I), ("grid_x", _I), ("tap", _I)]
+                ("C", _I), ("Ktot", _I), ("koff", _I), ("kind", _I), ("nlr", _I), ("nwn", _I), ("nchunks", _I), ("grid_x", _I), ("tap", _I), ("gb", _P)]
 
 
 class _GnBwdArgs(C.Structure):
@@ -207,7 +207,7 @@ class TrainCtx:
             return nwn, nlr, -(-(B * H * W) // nlr)
         raise native.CtddError(f"weight gradient: no chunk of a {H}x{W} grid fits the kernel's staging slots")
 
-    def _wgrad_entry(self, x_t, gy, N, ldy, Cseg, e, kind, B, H, W, Hin, Win):
+    def _wgrad_entry(self, x_t, gy, N, ldy, Cseg, e, kind, B, H, W, Hin, Win, gb=None):
         """Queue the weight gradient of one K-segment; all of them run as ONE table launch at the end of the backward plan."""
         eng = self.eng
         wk = {SEG_3x3: WG_3x3, SEG_1x1: WG_1x1, SEG_3x3_S2: WG_3x3_S2}[kind]
@@ -219,6 +219,7 @@ class TrainCtx:
             a.gw = e["gw_ptr"]
             a.B, a.H, a.W, a.Hin, a.Win, a.N, a.ldy, a.C, a.Ktot, a.koff = B, H, W, Hin, Win, N, ldy, Cseg, e["Ktot"], e["koff"]
             a.kind, a.nlr, a.nwn, a.nchunks, a.tap = wk, nlr, nwn, nchunks, tap
+            a.gb = gb if tap == 0 else None              # (bias gradient: the column sums of gy, once per convolution)
             self.wgrad_entries.append(a)
 
     @staticmethod
@@ -346,6 +347,7 @@ class TrainCtx:
                 gyT = as_seg(gy, ldy)
                 # bias gradients (+ the per-sample time-projection gradient): per-(sample, channel) sums of the output gradient
                 bps = r["bias_params"]
+                bias_scr = None
                 if (bps or r["tb"] is not None) and not r.get("sums_done"):
                     out_bn, stride = None, 0
                     if r["tb"] is not None:
@@ -354,12 +356,11 @@ class TrainCtx:
                         launch(l.ctdd_unet_colsum, ptr(gy.f32), ptr(gy.hi), B, Ho * Wo, -(-N // 8) * 8, ldy, out_bn, stride, None,
                                label="time-projection gradient")
                     if bps:
-                        # sum over all pixels of gy = a weight gradient against an all-ones input: one more entry of the
-                        # weight-gradient table (kind 1x1, eight identical columns), column 0 copied out by the sums launch
-                        scr = zalloc(N * 8)
-                        self._wgrad_entry(ones, gy, N, ldy, 8, dict(gw_ptr=scr, Ktot=8, koff=0), SEG_1x1, B, Ho, Wo, Ho, Wo)
+                        # sum over all pixels of gy: rides on the staging of the convolution's first weight-gradient entry
+                        # (ctdd_wgrad_args.gb), copied to the parameters' gradients by the sums launch
+                        bias_scr = zalloc(N)
                         for bp in bps:
-                            sum_jobs.append((scr, 1, 0, 8, N, gptr(bp), 0))
+                            sum_jobs.append((bias_scr, 1, 0, 1, N, gptr(bp), 0))
                 # identity skip / residual
                 if r["res"] is not None:
                     gr = self.g(r["res"])
@@ -368,7 +369,8 @@ class TrainCtx:
                     gr.has = True
                 for (src, cs, skind), e in zip(r["segs"], r["per_seg"]):
                     one = skind == SEG_1x1
-                    self._wgrad_entry(src, gy, N, ldy, cs, e, skind, B, Ho, Wo, Ho if one else Hi, Wo if one else Wi)
+                    self._wgrad_entry(src, gy, N, ldy, cs, e, skind, B, Ho, Wo, Ho if one else Hi, Wo if one else Wi, gb=bias_scr)
+                    bias_scr = None
                     # data gradient of the segment: a convolution of gy with the flipped / transposed weights
                     gs = self.g(src)
                     packed = (None, e["dgrad"]) if eng.precise else (e["dgrad"], None)

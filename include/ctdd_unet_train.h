@@ -36,6 +36,8 @@ typedef struct {
   int nchunks;        /* CTDD_WG_3x3: ceil(B (H+1) / nlr); otherwise ceil(B H W / nlr)            */
   int grid_x;         /* workgroups that share the chunks of this entry (M-split)                 */
   int tap;            /* CTDD_WG_3x3_S2: the tap (0..8) this entry computes: nine entries per such convolution */
+  float* gb;          /* [N] fp32 or null: += sum over all pixels of dy[p][n] (the bias gradient; one entry per convolution
+                       * carries it -- of a stride-2 convolution's nine, the tap-0 entry), atomically accumulated   */
 } ctdd_wgrad_args;
 /* ONE launch for a table of n entries (blockIdx.z = entry): the backward plan defers all weight gradients to its end so
  * that equal-shaped convolutions fill the chip together with few M-split workgroups each (those meet in float atomics).

@@ -47,6 +47,7 @@ def _wgrad_case(case, f32, g):
     ntap = 1 if kind == 1 else 9
     koff, Ktot = 16, 16 + ntap * Cc + 8                        # the segment sits inside a wider packed matrix
     gw = torch.zeros((N, Ktot), dtype=torch.float32, device="cuda")
+    gb = torch.zeros((N,), dtype=torch.float32, device="cuda")
     ents = []
     for tap in (range(9) if kind == 2 else (0,)):
         a = ut._WgradArgs()
@@ -60,6 +61,7 @@ def _wgrad_case(case, f32, g):
             a.nlr = max(16, min(nlr, 2048 // vn, 2560 // vc) // 16 * 16)
         a.nchunks = -(-(B * (H + 1)) // a.nlr) if kind == 0 else -(-(B * H * W) // a.nlr)
         a.grid_x, a.tap = min(gx, a.nchunks), tap
+        a.gb = gb.data_ptr() if tap == 0 else None             # the bias gradient rides on one entry per convolution
         ents.append(a)
     # reference: autograd of the convolution on the same (rounded) operands
     w = torch.zeros((N, Cc, 3 if kind != 1 else 1, 3 if kind != 1 else 1), device="cuda", requires_grad=True)
@@ -68,7 +70,7 @@ def _wgrad_case(case, f32, g):
     assert out.shape[2:] == (H, W)
     out.backward(dy.float().permute(0, 3, 1, 2))
     ref = w.grad.permute(0, 2, 3, 1).reshape(N, ntap * Cc)       # [n][tap][c]
-    return ents, (x, dy), gw, ref, (koff, ntap * Cc)
+    return ents, (x, dy, gb), gw, ref, (koff, ntap * Cc)
 
 
 @pytest.mark.parametrize("f32", [False, True])
@@ -85,10 +87,12 @@ def test_wgrad_kernel(f32):
         dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
         _check(lib.ctdd_unet_wgrad(dev_tab.data_ptr(), C.addressof(tab), len(ents), int(f32), _stream()), lib)
     torch.cuda.synchronize()
-    for case, (_, _, gw, ref, (koff, width)) in zip(WGRAD_CASES, cases):
+    for case, (_, (_, dy, gb), gw, ref, (koff, width)) in zip(WGRAD_CASES, cases):
         got = gw[:, koff:koff + width]
         scale = ref.abs().max().item()
         assert (got - ref).abs().max().item() < 2e-5 * scale + 1e-6, (case, (got - ref).abs().max().item(), scale)
+        bref = dy.float().sum((0, 1, 2))                       # ctdd_wgrad_args.gb: column sums of dy over all pixels
+        assert (gb - bref).abs().max().item() < 2e-5 * bref.abs().max().item() + 1e-5, (case, "bias gradient")
         assert gw[:, :koff].abs().max().item() == 0 and gw[:, koff + width:].abs().max().item() == 0
 
 
