@@ -27,6 +27,12 @@ struct GemmArgs {
   const float* res;                            // [M][N] fp32 or null (added after the activation)
   float* out_f32; unsigned short* out_hi; unsigned short* out_lo;   // any subset: fp32, bf16, bf16(v - hi)
   int M, N, K, act;                            // act 0 none, 1 ReLU, 2 GELU (erf)
+  // training epilogues (hollow_train_kernels.hip's streams and rules, so that the separate passes they replace and their backward
+  // regenerate / read the same masks):
+  float drop_p; const uint64_t* rng; uint64_t layer;   // drop_p > 0: dropout of act(.) BEFORE the residual, keep flags
+                                               // Philox(rng[0], rng[1] * 4096 + layer, element / 4) as k_hollow_dropout / k_hollow_act
+  const unsigned short* mask_u;                // [M][N] bf16 or null: v <- mask_u != 0 ? v / (1 - drop_p) : 0 (the ReLU + dropout
+                                               // backward of k_hollow_relu_bf16: the saved output is the mask), no random numbers
 };
 
 using gbf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -134,6 +140,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs a) {
   // lane (a direct store is 4 or 2 bytes per lane: 2.2 TB/s in fp32, 1.2 in bf16 measured); read back row-major, a lane owns
   // four consecutive columns -> 16-byte residual loads and stores (8-byte in bf16).
   float* img = (float*)smem + wave * (32 * ILD);
+  const float inv_keep = a.drop_p > 0.0f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const uint64_t dseed = (a.drop_p > 0.0f && !a.mask_u) ? a.rng[0] : 0, dctr = (a.drop_p > 0.0f && !a.mask_u) ? a.rng[1] * 4096u + a.layer : 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -156,6 +164,15 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs a) {
         else if (a.act == 2) x[e] = 0.5f * x[e] * (1.0f + erff(x[e] * 0.70710678118654752f));
       }
       const size_t o = (size_t)grow * a.N + col;
+      if (a.mask_u) {                                            // (uniform branches: kernel arguments)
+        const uint2 mu = *(const uint2*)(a.mask_u + o);
+        x[0] = (mu.x & 0x7FFFu) ? x[0] * inv_keep : 0.0f; x[1] = (mu.x & 0x7FFF0000u) ? x[1] * inv_keep : 0.0f;
+        x[2] = (mu.y & 0x7FFFu) ? x[2] * inv_keep : 0.0f; x[3] = (mu.y & 0x7FFF0000u) ? x[3] * inv_keep : 0.0f;
+      } else if (a.drop_p > 0.0f) {
+        const u4 r = philox_row(dseed, dctr, (uint64_t)(o >> 2), 0x44524F50u);
+        x[0] = u01(r.x) >= a.drop_p ? x[0] * inv_keep : 0.0f; x[1] = u01(r.y) >= a.drop_p ? x[1] * inv_keep : 0.0f;
+        x[2] = u01(r.z) >= a.drop_p ? x[2] * inv_keep : 0.0f; x[3] = u01(r.w) >= a.drop_p ? x[3] * inv_keep : 0.0f;
+      }
       if (a.res) { const float4 r4 = *(const float4*)(a.res + o); x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w; }
       if (a.out_f32) *(float4*)(a.out_f32 + o) = make_float4(x[0], x[1], x[2], x[3]);
       if (a.out_hi) {
@@ -182,6 +199,7 @@ extern "C" int ctdd_gemm_bf16(const void* args_, void* stream) {
   for (int i = 0; i < a.nseg; ++i) CTDD_REQUIRE(a.a[i], CTDD_EINVAL, "gemm: null segment %d", i);
   CTDD_REQUIRE(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.K > 0 && a.K % 64 == 0, CTDD_ERANGE, "gemm: M=%d N=%d K=%d (K %% 64 == 0, N %% 4 == 0)", a.M, a.N, a.K);
   CTDD_REQUIRE(a.act >= 0 && a.act <= 2, CTDD_EINVAL, "gemm: act %d", a.act);
+  CTDD_REQUIRE(a.drop_p >= 0.0f && a.drop_p < 1.0f && (a.drop_p == 0.0f || a.mask_u || a.rng), CTDD_EINVAL, "gemm: dropout %g without a stream", (double)a.drop_p);
   hipStream_t st = (hipStream_t)stream;
   // Tile / chunk selection from measurements (scratch bench over the training and inference shapes, rows ~ 3e4):
   //   N <= 128               64 x 128 tiles, two chunks of 64 in flight            (K = 1024: 21.5 us vs 29.3 with 128 x 128 tiles)

@@ -39,7 +39,7 @@ class _LnArgs(C.Structure):
 
 class _GemmArgs(C.Structure):
     _fields_ = [("a", _P * 3), ("nseg", _I), ("w", _P), ("bias", _P), ("res", _P), ("out_f32", _P), ("out_hi", _P), ("out_lo", _P),
-                ("M", _I), ("N", _I), ("K", _I), ("act", _I)]
+                ("M", _I), ("N", _I), ("K", _I), ("act", _I), ("drop_p", _F), ("rng", _P), ("layer", C.c_uint64), ("mask_u", _P)]
 
 
 class _AttnArgs(C.Structure):

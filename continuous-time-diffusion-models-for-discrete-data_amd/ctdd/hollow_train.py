@@ -89,19 +89,31 @@ def _p(t):
 
 
 # ---------------------------------------------------------------------- launch helpers (no autograd)
-def _gemm(x, w, bias, res, rows, K, N, bf16, act=0, want_hi=False, want_f32=True):
+def _gemm_fusable(K, N, bf16):
+    """The plain GEMM kernel takes this product (its epilogue can then carry a dropout or a ReLU-backward mask)."""
+    return bool(bf16 and USE_GEMM_KERNEL and K % 64 == 0 and N % 8 == 0)
+
+
+def _gemm(x, w, bias, res, rows, K, N, bf16, act=0, want_hi=False, want_f32=True, drop=None, mask_u=None):
     """out[rows][N] = act(x[rows][K] @ w[N][K]^T (+ bias)) (+ res) -> (fp32 out or None, bf16 copy or None).
-    x, w: fp32, or bf16 when `bf16`."""
+    x, w: fp32, or bf16 when `bf16`.  drop = (p, rng, layer): dropout of act(.) before the residual, in the epilogue (the masks of
+    _dropout / _act); mask_u (+ drop = (p, None, 0)): the ReLU + dropout backward against the saved output -- both only where
+    _gemm_fusable says the plain GEMM kernel runs."""
     l = lib()
     dev = x.device
     out = torch.empty((rows, N), dtype=torch.float32, device=dev) if want_f32 else None
     out_hi = torch.empty((rows, N), dtype=torch.bfloat16, device=dev) if want_hi else None
-    if bf16 and USE_GEMM_KERNEL and K % 64 == 0 and N % 8 == 0:
+    if _gemm_fusable(K, N, bf16):
         g = _GemmArgs()
         g.a[0], g.nseg, g.w, g.bias, g.res = x.data_ptr(), 1, w.data_ptr(), _p(bias), _p(res)
         g.out_f32, g.out_hi, g.M, g.N, g.K, g.act = _p(out), _p(out_hi), rows, N, K, act
+        if drop is not None:
+            g.drop_p, g.rng, g.layer = float(drop[0]), _p(drop[1]), int(drop[2])
+        g.mask_u = _p(mask_u)
         _ck(l.ctdd_gemm_bf16(C.byref(g), _st()), "ctdd_gemm_bf16")
         return out, out_hi
+    if drop is not None or mask_u is not None:
+        raise native.CtddError("_gemm: dropout / mask epilogues exist in the plain GEMM kernel only")
     a = _ConvArgs()
     a.nseg = 1
     a.seg[0].C, a.seg[0].kind = K, SEG_1x1
@@ -466,11 +478,11 @@ class AttnBlockFn(torch.autograd.Function):
         qkv, _ = _gemm(z_op, pk_in[0], b_in.detach(), None, R, E, 3 * E, bf16)
         att, att_hi, stats = _attention_fwd(qkv, None, None, B, D, D, H, hd, mode, p_att, rng if p_att > 0 else None, l_att, bf16)
         att_op = att_hi if bf16 else att
-        if p_drop > 0.0:
+        if p_drop > 0.0 and not _gemm_fusable(E, E, bf16):
             o, _ = _gemm(att_op, pk_out[0], b_out.detach(), None, R, E, E, bf16)
             out, _ = _dropout(o, p_drop, rng, l_drop, res=h.view(R, E))
-        else:
-            out, _ = _gemm(att_op, pk_out[0], b_out.detach(), h.view(R, E), R, E, E, bf16)
+        else:                                                  # h + dropout(out_proj(.)) in the epilogue
+            out, _ = _gemm(att_op, pk_out[0], b_out.detach(), h.view(R, E), R, E, E, bf16, drop=(p_drop, rng, l_drop) if p_drop > 0.0 else None)
         ctx.save_for_backward(h, ln_w, ln_b, w_in, w_out, z_op, qkv, att, att_op, stats, rng)
         ctx.meta = meta
         return out.view(B, D, E)
@@ -508,8 +520,10 @@ class MlpBlockFn(torch.autograd.Function):
         z_op = (z_hi if bf16 else z).view(R, E)
         if bf16:
             # ReLU in the GEMM epilogue; with dropout one in-place pass over the bf16 tensor (relu is idempotent)
-            _, u_op = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, True, act=1, want_hi=True, want_f32=False)
-            if p_drop > 0.0:
+            fuse1 = _gemm_fusable(E, M, True)                  # dropout in the epilogue too (same masks as the in-place pass)
+            _, u_op = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, True, act=1, want_hi=True, want_f32=False,
+                            drop=(p_drop, rng, l1) if (fuse1 and p_drop > 0.0) else None)
+            if p_drop > 0.0 and not fuse1:
                 _ck(lib().ctdd_hollow_relu_bf16(u_op.data_ptr(), None, u_op.data_ptr(), u_op.numel(), float(p_drop), rng.data_ptr(), int(l1), _st()),
                     "ctdd_hollow_relu_bf16")
             pre = u_op
@@ -519,11 +533,11 @@ class MlpBlockFn(torch.autograd.Function):
         else:
             pre, _ = _gemm(z_op, pk1[0], b1.detach(), None, R, E, M, False, act=1)     # relu(pre): same ReLU mask
             u_op = pre
-        if p_drop > 0.0:
+        if p_drop > 0.0 and not _gemm_fusable(M, E, bf16):
             o, _ = _gemm(u_op, pk2[0], None, None, R, M, E, bf16)
             out, _ = _dropout(o, p_drop, rng, l2, res=h.view(R, E))
-        else:
-            out, _ = _gemm(u_op, pk2[0], None, h.view(R, E), R, M, E, bf16)
+        else:                                                  # h + dropout(fc2(u)) in the epilogue
+            out, _ = _gemm(u_op, pk2[0], None, h.view(R, E), R, M, E, bf16, drop=(p_drop, rng, l2) if p_drop > 0.0 else None)
         ctx.save_for_backward(h, ln_w, ln_b, w1, w2, z_op, pre, u_op, rng)
         ctx.meta = meta
         return out.view(B, D, E)
@@ -538,9 +552,12 @@ class MlpBlockFn(torch.autograd.Function):
         if bf16:
             do_hi = _dropout(dout.view(R, E), p_drop, rng, l2, want_f32=False, want_hi=True)[1]
             dw2, _ = _wgrad(u_op, do_hi, R, E, E, M, True, False, (zw2, None))
-            _, du_hi = _gemm(do_hi, pk2[1], None, None, R, E, M, True, want_hi=True, want_f32=False)
-            _ck(lib().ctdd_hollow_relu_bf16(du_hi.data_ptr(), u_op.data_ptr(), du_hi.data_ptr(), du_hi.numel(), float(p_drop), None, 0, _st()),
-                "ctdd_hollow_relu_bf16")
+            if _gemm_fusable(E, M, True):                      # du * [u != 0] / (1 - p) in the epilogue of du = do W2
+                _, du_hi = _gemm(do_hi, pk2[1], None, None, R, E, M, True, want_hi=True, want_f32=False, drop=(p_drop, None, 0), mask_u=u_op)
+            else:
+                _, du_hi = _gemm(do_hi, pk2[1], None, None, R, E, M, True, want_hi=True, want_f32=False)
+                _ck(lib().ctdd_hollow_relu_bf16(du_hi.data_ptr(), u_op.data_ptr(), du_hi.data_ptr(), du_hi.numel(), float(p_drop), None, 0, _st()),
+                    "ctdd_hollow_relu_bf16")
             dz, dw1, db1 = _linear_bwd(z_op, w1, None, R, True, True, dy_hi=du_hi, wt=pk1[1], bufs=(zw1, zb1))
         else:
             do = _dropout(dout.view(R, E), p_drop, rng, l2)[0] if p_drop > 0.0 else dout.view(R, E)

@@ -46,6 +46,10 @@ int ctdd_hollow_put_rows(const float* src, float* dst, void* dst_bf16, void* dst
 typedef struct {
   const void* a[3]; int nseg; const void* w; const float* bias; const float* res;
   float* out_f32; void* out_hi; void* out_lo; int M, N, K, act;
+  /* training epilogues (hollow_networks.py:343-420: the Dropout layers of the blocks), the masks of ctdd_hollow_dropout / _act:
+   * drop_p > 0 with rng = {seed, step}: out = dropout(act(.)) + res, keep flags Philox(seed, step * 4096 + layer, element / 4);
+   * mask_u ([M][N] bf16): out = mask_u != 0 ? . / (1 - drop_p) : 0 -- the ReLU + dropout backward, the saved output as the mask */
+  float drop_p; const uint64_t* rng; uint64_t layer; const void* mask_u;
 } ctdd_gemm_args;
 int ctdd_gemm_bf16(const void* gemm_args, void* stream);
 

@@ -73,3 +73,42 @@ def test_gemm_rejects_bad_shapes():
         _run(64, 48, 64)                                                    # K % 64 != 0
     with pytest.raises(native.CtddError):
         _run(64, 64, 6)                                                     # N % 4 != 0
+
+
+@pytest.mark.parametrize("M,K,N", [(700, 128, 1024), (513, 1024, 128), (257, 192, 264)])
+def test_gemm_training_epilogues_match_the_separate_passes(M, K, N):
+    """drop_p / rng / layer: out = dropout(act(.)) + res with the keep flags of ctdd_hollow_dropout (Philox(seed, step * 4096 +
+    layer, element / 4)): bit-identical to the plain product followed by that pass.  mask_u: the ReLU + dropout backward of
+    ctdd_hollow_relu_bf16 (saved output as the mask) against the same rule in torch."""
+    from ctdd import hollow_train as ht
+    from ctdd.hollow_engine import _GemmArgs
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().to(torch.bfloat16)
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).cuda()
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device="cuda")
+    p, layer = 0.25, 5
+    st = torch.cuda.current_stream().cuda_stream
+
+    def gemm(res, drop, mask=None, act=0):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        a = _GemmArgs()
+        a.a[0], a.nseg, a.w, a.bias, a.res = x.data_ptr(), 1, w.data_ptr(), b.data_ptr(), ht._p(res)
+        a.out_f32, a.M, a.N, a.K, a.act = out.data_ptr(), M, N, K, act
+        if drop:
+            a.drop_p, a.rng, a.layer = p, (None if mask is not None else rng.data_ptr()), layer
+        a.mask_u = ht._p(mask)
+        ht._ck(ht.lib().ctdd_gemm_bf16(C.byref(a), st), "ctdd_gemm_bf16")
+        return out
+
+    plain = gemm(None, False, act=1)
+    fused = gemm(r, True, act=1)
+    sep, _ = ht._dropout(plain, p, rng, layer, res=r)                       # the pass the epilogue replaces
+    assert torch.equal(fused, sep)
+    kept = (fused - r) != 0
+    assert 0.6 < float(kept.float().mean()) / float((plain != 0).float().mean()) < 0.9      # ~ 1 - p of the non-zero entries survive
+    u = torch.relu(torch.randn(M, N, generator=g)).cuda().to(torch.bfloat16)             # a saved forward output: zeros = dropped / clipped
+    got = gemm(None, True, mask=u)
+    ref = torch.where(u != 0, gemm(None, False) / (1.0 - p), torch.zeros((), device="cuda"))
+    assert torch.allclose(got, ref, rtol=1e-6, atol=0)
