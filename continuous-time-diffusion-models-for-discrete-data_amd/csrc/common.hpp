@@ -47,10 +47,10 @@ struct u4 {
   uint32_t x, y, z, w;
 };
 
-__host__ __device__ inline u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                            uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+__host__ __device__ inline u4 philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -62,6 +62,15 @@ __host__ __device__ inline u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     k1 += 0xBB67AE85u;
   }
   return u4{c0, c1, c2, c3};
+}
+
+__host__ __device__ inline u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32_r<10>(c0, c1, c2, c3, k0, k1);
+}
+// Seven rounds (Random123's smallest Crush-resistant Philox4x32): the attention-probability dropout of the hollow training
+// kernels only, where the generator is ~40 % of the instructions and nothing replays the stream outside those kernels.
+__host__ __device__ inline u4 philox_row7(uint64_t seed, uint64_t offset, uint64_t row, uint32_t draw) {
+  return philox4x32_r<7>((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)offset, draw, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 // counter = (row_lo, row_hi, offset, draw), key = seed

@@ -189,12 +189,12 @@ __device__ inline bool attn_allowed(int mode, int Tq, int i, int j) {
 }
 // Dropout on the attention probabilities: one Philox block per (query, EIGHT consecutive keys), its 128 bits as eight 16-bit
 // uniforms (Philox4x32-10 is 20 quarter-rate 32 x 32 -> 64 multiplies: at one block per four probabilities it was ~45 % of the
-// matrix-core kernels' instructions).  keep_k = u16_k >= thr, thr = round(p 65536): the rate in force is thr / 65536 (|error| <
+// matrix-core kernels' instructions; this stream runs seven rounds, common.hpp: philox_row7).  keep_k = u16_k >= thr, thr = round(p 65536): the rate in force is thr / 65536 (|error| <
 // 8e-6), and 1 / (1 - thr / 65536) is the rescale every kernel uses.
 __device__ inline unsigned attn_thr(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
 __device__ inline float attn_inv_keep(float p) { return p > 0.0f ? 1.0f / (1.0f - (float)attn_thr(p) * (1.0f / 65536.0f)) : 1.0f; }
 __device__ inline unsigned keep8v(uint64_t seed, uint64_t ctr, uint64_t oct, unsigned thr) {
-  const u4 r = philox_row(seed, ctr, oct, 0x4154544Eu);
+  const u4 r = philox_row7(seed, ctr, oct, 0x4154544Eu);
   return ((r.x & 0xFFFFu) >= thr ? 1u : 0u) | ((r.x >> 16) >= thr ? 2u : 0u) | ((r.y & 0xFFFFu) >= thr ? 4u : 0u) | ((r.y >> 16) >= thr ? 8u : 0u) |
          ((r.z & 0xFFFFu) >= thr ? 16u : 0u) | ((r.z >> 16) >= thr ? 32u : 0u) | ((r.w & 0xFFFFu) >= thr ? 64u : 0u) | ((r.w >> 16) >= thr ? 128u : 0u);
 }
