@@ -6,9 +6,11 @@ import torch
 import lib.models.models, lib.losses.losses, lib.training.training, lib.optimizers.optimizers  # noqa
 import lib.models.model_utils as mu, lib.losses.losses_utils as lu, lib.training.training_utils as tu, lib.optimizers.optimizers_utils as ou
 from config.cifar10_config.config_tauUnet_cifar10 import get_config
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-for engine in ("hip", "torch"):
+B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 32
+_over = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}      # cfg.model knobs (then the HIP plan only)
+for engine in (("hip",) if _over else ("hip", "torch")):
     cfg = get_config(); cfg.device = "cuda"; cfg.model.engine = engine
+    for k_, v_ in _over.items(): setattr(cfg.model, k_, v_)
     torch.manual_seed(0)
     model = mu.create_model(cfg, torch.device("cuda"))
     state = {"model": model, "optimizer": ou.get_optimizer(model.parameters(), cfg), "n_iter": 0}
@@ -16,7 +18,7 @@ for engine in ("hip", "torch"):
     mb = torch.randint(0, 256, (B, 3, 32, 32), device="cuda")
     for _ in range(3): l = step.step(state, loss, mb); state["n_iter"] += 1
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): l = step.step(state, loss, mb); state["n_iter"] += 1
+    for _ in range(20): l = step.step(state, loss, mb); state["n_iter"] += 1
     torch.cuda.synchronize()
-    print("%-5s B=%d loss=%s: %.2f ms/step  loss %.3f" % (engine, B, cfg.loss.name, (time.perf_counter() - t0) / 5 * 1e3, float(l)), flush=True)
+    print("%-5s B=%d loss=%s: %.2f ms/step  loss %.3f" % (engine, B, cfg.loss.name, (time.perf_counter() - t0) / 20 * 1e3, float(l)), flush=True)
     del model, state
