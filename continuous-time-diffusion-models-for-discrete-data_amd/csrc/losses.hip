@@ -189,6 +189,9 @@ struct ElboArgs {
   int B, D, S; float eps, elbo_scale, nll_scale;
   float reg_scale;    // weight of the regulariser term (= elbo_scale in the one-forward-pass objective; the two-pass objective runs
                       // the kernel once per network output with one of the two term weights at zero)
+  float* RT;          // (B,S,S) or null: RT[b][x][s] = R[b][s][x], written by k_elbo_atab (all column blocks) so that a row's forward
+                      // rates into its state x are ONE coalesced table row (the column gather R[s][x] per (row, state) was a cache
+                      // line per lane: the outer / G passes ran at a third of their memory time)
   float* Atab;        // (B,S,S): A[b][x][s0]
   float* base_sum;    // (B)
   float* u;           // (B,D,S)
@@ -248,6 +251,11 @@ __global__ __launch_bounds__(256) void k_elbo_atab(const ElboArgs a) {
 #pragma unroll
     for (int r = 0; r < LRB; ++r)
       if (s00 + r < S) a.Atab[((size_t)b * S + t) * S + s00 + r] = acc[r] / (qrow[r][t] + a.eps);
+    if (a.RT) {
+#pragma unroll
+      for (int r = 0; r < LRB; ++r)
+        if (s00 + r < S) a.RT[((size_t)b * S + t) * S + s00 + r] = R[(size_t)(s00 + r) * S + t];
+    }
   }
   if (blockIdx.x == 0) {                            // base_sum[b] = sum_d rs[x~_bd]
     float s = 0.0f;
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void k_elbo_fwd(const ElboArgs a) {
     if (act) {
       const size_t row = (size_t)b * D + d0 + r;
       if (PHASE == 0 && ok[r]) a.u[row * S + t] = acc[r];
-      const float orate = t == x[r] ? 0.0f : R[(size_t)t * S + x[r]];
+      const float orate = t == x[r] ? 0.0f : (a.RT ? a.RT[((size_t)b * S + x[r]) * S + t] : R[(size_t)t * S + x[r]]);
       const float qx0 = q[(size_t)x0[r] * S + t];
       const float qx0xt = q[(size_t)x0[r] * S + x[r]] + a.eps;
       const float Z = bsum + R[(size_t)x[r] * S + x[r]] - R[(size_t)t * S + t];      // base_sum - rs[x] + rs[s]
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
     // G[s] = c_b Wt[s] / (u[s] + eps)
     float G = 0.0f;
     if (act && PHASE != 2) {
-      const float orate = t == x[r] ? 0.0f : R[(size_t)t * S + x[r]];
+      const float orate = t == x[r] ? 0.0f : (a.RT ? a.RT[((size_t)b * S + x[r]) * S + t] : R[(size_t)t * S + x[r]]);
       const float qx0 = q[(size_t)x0[r] * S + t];
       const float qx0xt = q[(size_t)x0[r] * S + x[r]] + a.eps;
       G = cb * orate * (qx0 / qx0xt) / (a.u[row * S + t] + a.eps);
@@ -553,9 +561,9 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
 }  // namespace ctdd
 
 extern "C" int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S) {
-  // Atab (B,S,S) f32 | u (B,D,S) f32 | rows (B*D,4) f64 | base_sum (B) f32 | cb (B) f32 | sums (B,4) f64   (each 256-B aligned)
+  // Atab (B,S,S) f32 | u (B,D,S) f32 | rows (B*D,4) f64 | base_sum (B) f32 | cb (B) f32 | sums (B,4) f64 | RT (B,S,S) f32   (each 256-B aligned)
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al((int64_t)B * S * S * 4) + al((int64_t)B * D * S * 4) + al((int64_t)B * D * 32) + 2 * al((int64_t)B * 4) + al((int64_t)B * 32);
+  return 2 * al((int64_t)B * S * S * 4) + al((int64_t)B * D * S * 4) + al((int64_t)B * D * 32) + 2 * al((int64_t)B * 4) + al((int64_t)B * 32);
 }
 
 extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, const int32_t* x_tilde, const float* qt0, const float* qt0T,
@@ -583,7 +591,8 @@ extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, co
   a.rows = (double*)sp; sp += al((int64_t)B * D * 32);
   a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
   a.cb = (float*)sp; sp += al((int64_t)B * 4);
-  double* sums = (double*)sp;
+  double* sums = (double*)sp; sp += al((int64_t)B * 32);
+  a.RT = (float*)sp;
   a.grad = grad_logits; a.out_loss = out_loss; a.ll_in = 0;
   hipStream_t st = (hipStream_t)stream;
   const dim3 rg((D + LRB - 1) / LRB, B), gg((D + 127) / 128, B);
@@ -749,6 +758,7 @@ static int score_elbo_impl(const float* logits, const int32_t* x0, const int32_t
   a.base_sum = (float*)sp; sp += al((int64_t)B * 4);
   a.cb = (float*)sp; sp += al((int64_t)B * 4);
   double* sums = (double*)sp;
+  a.RT = nullptr;                                       // (k_elbo_atab runs its first column block only here)
   a.grad = grad_logits; a.out_loss = out_loss; a.ll_in = ll_in;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)B * D;
