@@ -120,6 +120,99 @@ __global__ __launch_bounds__(256) void k_hollow_layernorm(const HollowLnArgs a) 
   for (int e = lane; e < E; e += 64) emit(e, (x[e] + (y ? y[e] : 0.0f) - mean) * rstd * a.gamma[e] + a.beta[e]);
 }
 
+// The same for widths whose rows are whole 16-byte vectors per lane (E = 4 NV LPR, LPR | 64: E = 128, 256, 512 here): a lane
+// owns 4 NV consecutive-by-four columns, LPR lanes a row, so a wave instruction moves 64 / LPR rows as 16-byte loads and 8-byte
+// bf16 stores (one row per wave with 4-byte loads and 2-byte stores ran at 1.5 TB/s), PASSES row groups in flight per wave.
+template <int NV, int PASSES>
+__global__ __launch_bounds__(256) void k_hollow_layernorm_v4(const HollowLnArgs a, int LPR) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, E = a.E;
+  const int RPP = 64 / LPR, sub = lane % LPR, rsub = lane / LPR;
+  const int64_t rows = (int64_t)a.B * a.T;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wv) * (PASSES * RPP);
+  float4 g[NV], be[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int e = 4 * sub + 4 * LPR * v;
+    g[v] = *(const float4*)(a.gamma + e);
+    be[v] = *(const float4*)(a.beta + e);
+  }
+  float4 xv[PASSES][NV];
+  int bb[PASSES], jj[PASSES];
+  bool ok[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int64_t row = row0 + p * RPP + rsub;
+    ok[p] = row < rows;
+    const int64_t rc = ok[p] ? row : rows - 1;
+    bb[p] = (int)(rc / a.T); jj[p] = (int)(rc - (int64_t)bb[p] * a.T);
+    const float* x = a.x + (size_t)bb[p] * a.x_bs + (size_t)jj[p] * E;
+    const float* y = a.y ? a.y + (size_t)bb[p] * a.y_bs + (size_t)jj[p] * E : nullptr;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int e = 4 * sub + 4 * LPR * v;
+      float4 t = *(const float4*)(x + e);
+      if (y) { const float4 u = *(const float4*)(y + e); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      xv[p][v] = t;
+    }
+  }
+  auto lsum = [&](float (&v)[PASSES]) {             // over the LPR lanes of a row, all row groups at once (independent exchanges per step)
+    for (int o = LPR >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) v[p] += __shfl_xor(v[p], o, WAVE);
+    }
+  };
+  float mean[PASSES], rstd[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    float s_ = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s_ += (xv[p][v].x + xv[p][v].y) + (xv[p][v].z + xv[p][v].w);
+    mean[p] = s_;
+  }
+  lsum(mean);
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) mean[p] = mean[p] / (float)E;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    float q = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float d0 = xv[p][v].x - mean[p], d1 = xv[p][v].y - mean[p], d2 = xv[p][v].z - mean[p], d3 = xv[p][v].w - mean[p];
+      q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+    }
+    rstd[p] = q;
+  }
+  lsum(rstd);
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) rstd[p] = 1.0f / sqrtf(rstd[p] / (float)E + a.eps);
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    if (!ok[p]) continue;
+    float* o = a.out ? a.out + (size_t)bb[p] * a.out_bs + (size_t)jj[p] * E : nullptr;
+    unsigned short* oh = a.out_hi ? a.out_hi + (size_t)bb[p] * a.out_hi_bs + (size_t)jj[p] * E : nullptr;
+    unsigned short* ol = (oh && a.out_lo) ? a.out_lo + (size_t)bb[p] * a.out_hi_bs + (size_t)jj[p] * E : nullptr;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int e = 4 * sub + 4 * LPR * v;
+      float r[4] = {(xv[p][v].x - mean[p]) * rstd[p] * g[v].x + be[v].x, (xv[p][v].y - mean[p]) * rstd[p] * g[v].y + be[v].y,
+                    (xv[p][v].z - mean[p]) * rstd[p] * g[v].z + be[v].z, (xv[p][v].w - mean[p]) * rstd[p] * g[v].w + be[v].w};
+      if (a.film) {
+        const float4 fa = *(const float4*)(a.film + (size_t)bb[p] * a.film_stride + e), fb = *(const float4*)(a.film + (size_t)bb[p] * a.film_stride + E + e);
+        r[0] = fa.x * r[0] + fb.x; r[1] = fa.y * r[1] + fb.y; r[2] = fa.z * r[2] + fb.z; r[3] = fa.w * r[3] + fb.w;
+      }
+      if (o) *(float4*)(o + e) = make_float4(r[0], r[1], r[2], r[3]);
+      if (oh) {
+        const unsigned short h0 = hk_bf16(r[0]), h1 = hk_bf16(r[1]), h2 = hk_bf16(r[2]), h3 = hk_bf16(r[3]);
+        *(uint2*)(oh + e) = make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+        if (ol) {
+          const unsigned short l0 = hk_lo(r[0], h0), l1 = hk_lo(r[1], h1), l2 = hk_lo(r[2], h2), l3 = hk_lo(r[3], h3);
+          *(uint2*)(ol + e) = make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        }
+      }
+    }
+  }
+}
+
 // out[b][j][:] = p[b][j][:] + q[b][j][:], strided batches
 __global__ __launch_bounds__(256) void k_hollow_add(const float* __restrict__ p, int64_t p_bs, const float* __restrict__ q, int64_t q_bs,
                                                    float* __restrict__ out, unsigned short* __restrict__ out_hi,
@@ -507,6 +600,23 @@ extern "C" int ctdd_hollow_layernorm(const void* args_, void* stream) {
   const HollowLnArgs& a = *(const HollowLnArgs*)args_;
   CTDD_REQUIRE(a.x && a.gamma && a.beta && (a.out || a.out_hi) && a.B > 0 && a.T > 0 && a.E > 0, CTDD_EINVAL, "hollow layernorm: bad arguments");
   const int64_t rows = (int64_t)a.B * a.T;
+  // vector path: rows of whole 16-byte pieces, LPR = E / (4 NV) lanes per row with LPR | 64, 16-byte aligned rows and tables
+  const int NV = a.E > 256 ? 2 : 1, LPR = a.E / (4 * NV);
+  auto al16 = [](const void* p_) { return ((uintptr_t)p_ & 15) == 0; };
+  const bool vec = a.E % (4 * NV) == 0 && LPR >= 1 && LPR <= 64 && 64 % LPR == 0 && a.E <= 512 && a.x_bs % 4 == 0 && a.y_bs % 4 == 0 &&
+                   a.out_bs % 4 == 0 && a.out_hi_bs % 4 == 0 && a.film_stride % 4 == 0 && al16(a.x) && al16(a.y) && al16(a.out) && al16(a.gamma) &&
+                   al16(a.beta) && al16(a.film) && ((uintptr_t)a.out_hi & 7) == 0 && ((uintptr_t)a.out_lo & 7) == 0;
+  if (vec) {
+    const int RPP = 64 / LPR;
+    if (NV == 1) {
+      const int64_t per_wg = 4 * 4 * RPP;
+      hipLaunchKernelGGL((k_hollow_layernorm_v4<1, 4>), dim3((unsigned)((rows + per_wg - 1) / per_wg)), dim3(256), 0, (hipStream_t)stream, a, LPR);
+    } else {
+      const int64_t per_wg = 4 * 2 * RPP;
+      hipLaunchKernelGGL((k_hollow_layernorm_v4<2, 2>), dim3((unsigned)((rows + per_wg - 1) / per_wg)), dim3(256), 0, (hipStream_t)stream, a, LPR);
+    }
+    return finish_launch("k_hollow_layernorm_v4");
+  }
   hipLaunchKernelGGL(k_hollow_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return finish_launch("k_hollow_layernorm");
 }

@@ -168,6 +168,160 @@ __global__ __launch_bounds__(256) void k_hollow_ln_bwd(const LnBwdArgs a) {
   }
 }
 
+// The same with 16-byte vectors (E = 4 NV LPR, LPR | 64: every width the trainer runs -- 128, 256, 512): a lane owns 4 NV
+// columns, LPR lanes a row, a wave instruction moves 64 / LPR rows; the reductions run over LPR lanes.  (With a column per lane
+// and 4-byte loads the 28 800 x 128 call took 28.6 us for 59 MB; the rows' dependent load -> mean -> variance -> means -> store
+// chains need more bytes in flight per wave than that layout gives.)
+template <int NV>
+__global__ __launch_bounds__(256) void k_hollow_ln_bwd_v4(const LnBwdArgs a, int LPR) {
+  constexpr int RG = NV == 1 ? 4 : 2;
+  __shared__ float red[4][2][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, E = a.E;
+  const int RPP = 64 / LPR, sub = lane % LPR, rsub = lane / LPR;
+  const int wps = (a.T + a.rpw - 1) / a.rpw;                                  // waves per sample
+  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
+  const bool live = w < (int64_t)a.B * wps;
+  const int b = live ? (int)(w / wps) : 0, j0 = live ? (int)(w % wps) * a.rpw : 0, j1 = live ? min(j0 + a.rpw, a.T) : 0;
+  // sums over the LPR lanes of a row, all RG row groups at once (independent exchanges per step: one group at a time was a chain
+  // of 5 x RG dependent LDS round trips per reduction and made this kernel slower than the column-per-lane one)
+  auto lsum = [&](float (&v)[RG]) {
+    for (int o = LPR >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+      for (int r = 0; r < RG; ++r) v[r] += __shfl_xor(v[r], o, WAVE);
+    }
+  };
+  float4 g[NV], be[NV], fa[NV], sg[NV], sb[NV], sa[NV], sfb[NV];
+  const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int e = 4 * sub + 4 * LPR * v;
+    g[v] = *(const float4*)(a.gamma + e);
+    be[v] = *(const float4*)(a.beta + e);
+    fa[v] = a.film ? *(const float4*)(a.film + (size_t)b * a.film_stride + e) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    sg[v] = sb[v] = sa[v] = sfb[v] = z4;
+  }
+  for (int jb = j0; jb < j1; jb += RG * RPP) {
+    float h[RG][NV][4], d[RG][NV][4], s_[RG], q[RG];
+    bool ok[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      const int jr = jb + r * RPP + rsub;
+      ok[r] = jr < j1;
+      const int j = ok[r] ? jr : j1 - 1;
+      const float* x = a.x + (size_t)b * a.x_bs + (size_t)j * E;
+      const float* y = a.y ? a.y + (size_t)b * a.y_bs + (size_t)j * E : nullptr;
+      const float* dr = a.dout + (size_t)b * a.dout_bs + (size_t)j * E;
+      s_[r] = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int e = 4 * sub + 4 * LPR * v;
+        float4 t = *(const float4*)(x + e);
+        if (y) { const float4 u = *(const float4*)(y + e); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const float4 dd = ok[r] ? *(const float4*)(dr + e) : z4;              // rows past the run contribute nothing
+        h[r][v][0] = t.x; h[r][v][1] = t.y; h[r][v][2] = t.z; h[r][v][3] = t.w;
+        d[r][v][0] = dd.x; d[r][v][1] = dd.y; d[r][v][2] = dd.z; d[r][v][3] = dd.w;
+        s_[r] += (t.x + t.y) + (t.z + t.w);
+      }
+    }
+    lsum(s_);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) s_[r] = s_[r] / (float)E;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      q[r] = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float t = h[r][v][c] - s_[r]; q[r] = fmaf(t, t, q[r]); }
+    }
+    lsum(q);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) q[r] = 1.0f / sqrtf(q[r] / (float)E + a.eps);
+    float m1[RG], m2[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      m1[r] = m2[r] = 0.0f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float gv[4] = {g[v].x, g[v].y, g[v].z, g[v].w}, bv[4] = {be[v].x, be[v].y, be[v].z, be[v].w}, fv[4] = {fa[v].x, fa[v].y, fa[v].z, fa[v].w};
+        float* sgp = (float*)&sg[v]; float* sbp = (float*)&sb[v]; float* sap = (float*)&sa[v]; float* sfp = (float*)&sfb[v];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float xh = (h[r][v][c] - s_[r]) * q[r];
+          const float z = gv[c] * xh + bv[c];
+          const float dz = d[r][v][c] * fv[c];
+          sap[c] = fmaf(d[r][v][c], z, sap[c]); sfp[c] += d[r][v][c];
+          sgp[c] = fmaf(dz, xh, sgp[c]); sbp[c] += dz;
+          const float dxh = dz * gv[c];
+          h[r][v][c] = xh; d[r][v][c] = dxh;                                  // reuse the registers: xhat, dxhat
+          m1[r] += dxh; m2[r] = fmaf(dxh, xh, m2[r]);
+        }
+      }
+    }
+    lsum(m1); lsum(m2);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) { m1[r] = m1[r] / (float)E; m2[r] = m2[r] / (float)E; }
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      if (!ok[r]) continue;
+      const int j = jb + r * RPP + rsub;
+      float* dx = a.dx + (size_t)b * a.dx_bs + (size_t)j * E;
+      float* dy = (a.dy && a.y) ? a.dy + (size_t)b * a.dy_bs + (size_t)j * E : nullptr;
+      const float* dres = a.dres ? a.dres + (size_t)b * a.dres_bs + (size_t)j * E : nullptr;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int e = 4 * sub + 4 * LPR * v;
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = q[r] * (d[r][v][c] - m1[r] - h[r][v][c] * m2[r]);
+        float4 ox = make_float4(o[0], o[1], o[2], o[3]);
+        if (dres) { const float4 t = *(const float4*)(dres + e); ox.x += t.x; ox.y += t.y; ox.z += t.z; ox.w += t.w; }
+        else if (a.acc_dx) { const float4 t = *(const float4*)(dx + e); ox.x += t.x; ox.y += t.y; ox.z += t.z; ox.w += t.w; }
+        *(float4*)(dx + e) = ox;
+        if (dy) {
+          float4 oy = make_float4(o[0], o[1], o[2], o[3]);
+          if (a.acc_dy) { const float4 t = *(const float4*)(dy + e); oy.x += t.x; oy.y += t.y; oy.z += t.z; oy.w += t.w; }
+          *(float4*)(dy + e) = oy;
+        }
+      }
+    }
+  }
+  // the row sub-groups of the wave hold partial sums of the same columns
+  auto rsum4 = [&](float4& v) {
+    for (int o = LPR; o < 64; o <<= 1) {
+      v.x += __shfl_xor(v.x, o, WAVE); v.y += __shfl_xor(v.y, o, WAVE); v.z += __shfl_xor(v.z, o, WAVE); v.w += __shfl_xor(v.w, o, WAVE);
+    }
+  };
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { rsum4(sg[v]); rsum4(sb[v]); }
+  if (a.dfilm) {                                                               // per-sample sums: few waves per address
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      rsum4(sa[v]); rsum4(sfb[v]);
+      if (live && rsub == 0) {
+        const int e = 4 * sub + 4 * LPR * v;
+        float* da = a.dfilm + (size_t)b * 2 * E + e;
+        atomicAdd(da, sa[v].x); atomicAdd(da + 1, sa[v].y); atomicAdd(da + 2, sa[v].z); atomicAdd(da + 3, sa[v].w);
+        atomicAdd(da + E, sfb[v].x); atomicAdd(da + E + 1, sfb[v].y); atomicAdd(da + E + 2, sfb[v].z); atomicAdd(da + E + 3, sfb[v].w);
+      }
+    }
+  }
+  if (rsub == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int e = 4 * sub + 4 * LPR * v;
+      *(float4*)(&red[wv][0][e]) = sg[v];
+      *(float4*)(&red[wv][1][e]) = sb[v];
+    }
+  }
+  __syncthreads();
+  const int rep = a.nrep > 1 ? (int)(blockIdx.x % (unsigned)a.nrep) : 0;
+  for (int idx = threadIdx.x; idx < 2 * E; idx += 256) {
+    const int which = idx / E, e = idx % E;
+    atomicAdd((which ? a.dbeta : a.dgamma) + (size_t)rep * a.rep_stride + e, red[0][which][e] + red[1][which][e] + red[2][which][e] + red[3][which][e]);
+  }
+}
+
 // ============================================================================ attention, training mode
 // rows as in hollow_kernels.hip: q (b, i) at q + b*q_bs + i*q_rs + h*hd etc.; mode 0 causal, 1 anti-causal, 2 readout.
 // dropout (nn.MultiheadAttention's attention dropout): out_i = sum_j softmax(s)_ij keep_ij / (1 - p) v_j.
@@ -898,9 +1052,23 @@ extern "C" int ctdd_hollow_layernorm_bwd(const void* args_, void* stream) {
   LnBwdArgs a = *(const LnBwdArgs*)args_;
   CTDD_REQUIRE(a.x && a.gamma && a.beta && a.dout && a.dx && a.dgamma && a.dbeta, CTDD_EINVAL, "layernorm bwd: null buffer");
   CTDD_REQUIRE(a.E >= 1 && a.E <= 512 && a.B > 0 && a.T > 0, CTDD_ERANGE, "layernorm bwd: E=%d (<= 512) B=%d T=%d", a.E, a.B, a.T);
-  if (a.rpw <= 0) a.rpw = 16;
+  const int NV = a.E > 256 ? 2 : 1, LPR = a.E / (4 * NV);
+  auto al16 = [](const void* p_) { return ((uintptr_t)p_ & 15) == 0; };
+  const bool vec = a.E % (4 * NV) == 0 && LPR >= 1 && LPR <= 64 && 64 % LPR == 0 && a.x_bs % 4 == 0 && a.y_bs % 4 == 0 && a.dout_bs % 4 == 0 &&
+                   a.dx_bs % 4 == 0 && a.dy_bs % 4 == 0 && a.dres_bs % 4 == 0 && a.film_stride % 4 == 0 && al16(a.x) && al16(a.y) && al16(a.dout) &&
+                   al16(a.dx) && al16(a.dy) && al16(a.dres) && al16(a.gamma) && al16(a.beta) && al16(a.film);
+  // rows per wave (0 = the kernel's own choice): one iteration of its row groups -- (4 or 2 groups) x (64 / LPR rows) on the
+  // vector path, four rows on the column-per-lane path
+  if (a.rpw <= 0) a.rpw = vec ? (NV == 1 ? 4 : 2) * (64 / LPR) : 4;
   const int64_t waves = (int64_t)a.B * ((a.T + a.rpw - 1) / a.rpw);
   const dim3 grid((unsigned)((waves + 3) / 4));
+  {
+    if (vec) {
+      if (NV == 1) hipLaunchKernelGGL(k_hollow_ln_bwd_v4<1>, grid, dim3(256), 0, (hipStream_t)stream, a, LPR);
+      else hipLaunchKernelGGL(k_hollow_ln_bwd_v4<2>, grid, dim3(256), 0, (hipStream_t)stream, a, LPR);
+      return finish_launch("k_hollow_ln_bwd_v4");
+    }
+  }
   if (a.E <= 128) hipLaunchKernelGGL(k_hollow_ln_bwd<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (a.E <= 256) hipLaunchKernelGGL(k_hollow_ln_bwd<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_hollow_ln_bwd<8>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -280,7 +280,7 @@ def _layernorm_bwd(x, y, gamma, beta, film, eps, dout, dres=None, rep=None):
     a.x, a.y, a.x_bs, a.y_bs = x.data_ptr(), _p(y), T * E, T * E
     a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
     a.film, a.film_stride = _p(film), 0 if film is None else film.shape[1]
-    a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 4
+    a.dout, a.dout_bs, a.B, a.T, a.E, a.rpw = dout.data_ptr(), T * E, B, T, E, 0      # (rows per wave: the launcher's choice)
     a.dx, a.dx_bs, a.acc_dx = dx.data_ptr(), T * E, 0
     a.dgamma, a.dbeta, a.dfilm = rep.data_ptr(), rep.data_ptr() + 4 * E, _p(dfilm)
     a.nrep, a.rep_stride = rep.shape[0], 2 * E

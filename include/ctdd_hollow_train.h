@@ -16,7 +16,9 @@ extern "C" {
 #endif
 
 /* backward of ctdd_hollow_layernorm: out = FiLM_b(LayerNorm(x (+ y))).  dx (and dy) (+)= ...; dgamma / dbeta [E] and
- * dfilm [B][2E] are ATOMICALLY ACCUMULATED (zero them first).  E <= 512. */
+ * dfilm [B][2E] are ATOMICALLY ACCUMULATED (zero them first).  E <= 512.  rpw: rows per wave, 0 = the launcher's choice (one
+ * pass of the kernel's row groups).  Widths of whole 16-byte vectors per lane (E = 128, 256, 512 with 16-byte aligned rows) run
+ * a vector kernel: a lane owns four consecutive columns, E / 4 lanes a row. */
 typedef struct {
   const float* x; const float* y; int64_t x_bs, y_bs; const float* gamma; const float* beta; float eps;
   const float* film; int film_stride; const float* dout; int64_t dout_bs; int B, T, E, rpw;
