@@ -558,6 +558,110 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
       a.grad[((size_t)b * D + d0 + r) * S + t] = p[r] * (dp[r] - pdot[r]) + a.nll_scale * (p[r] - (t == x0[r] ? 1.0f : 0.0f));
 }
 
+// ---- S = 256: the four row passes around the two matrix-core GEMMs with a WAVE per row (a lane owns four consecutive states:
+// one 16-byte load per table row and lane, reductions inside the wave).  The workgroup-per-eight-rows kernels above (thread =
+// state) spend their time in block reductions -- two barriers each, six of them in a forward pass -- and the second forward
+// pass re-formed a softmax it does not use: 85 / 100 / 33 / 68 us for the four passes at 64 x 784 rows.  MODE 0: fwd<1> (rvec,
+// reg / nll sums), 1: fwd<2> (outer / norm sums from u), 2: bwd<1> (G), 3: bwd<2> (d/dlogits from dr).  RT must be set.
+constexpr int RV_ROWS = 4;                                     // rows per wave, two at a time
+template <int MODE>
+__global__ __launch_bounds__(256) void k_elbo_rowsv(const ElboArgs a) {
+  constexpr int S = 256;
+  const int D = a.D, b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, s0 = 4 * lane;
+  const int d0 = (blockIdx.x * 4 + wv) * RV_ROWS;
+  const float* q = a.q + (size_t)b * S * S;
+  const float* qT = a.qT + (size_t)b * S * S;
+  const float* R = a.R + (size_t)b * S * S;
+  const float* RT = a.RT + (size_t)b * S * S;
+  const float* At = a.Atab + (size_t)b * S * S;
+  float rdiag[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float bsum = 0.0f, cb = 0.0f;
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rdiag[c] = R[(size_t)(s0 + c) * S + s0 + c];
+    bsum = a.base_sum[b];
+  }
+  if (MODE == 2) cb = a.cb[b];
+#pragma unroll
+  for (int r2 = 0; r2 < RV_ROWS; r2 += 2) {
+    float4 lg[2], t1[2], t2[2], t3[2];
+    int x[2], x0[2];
+    bool ok[2];
+    size_t row[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                                // everything the two rows need, requested together
+      const int d = d0 + r2 + e;
+      ok[e] = d < D;
+      row[e] = (size_t)b * D + (ok[e] ? d : D - 1);
+      x[e] = min(max(a.xt[row[e]], 0), S - 1);
+      x0[e] = min(max(a.x0[row[e]], 0), S - 1);
+      if (MODE == 0 || MODE == 3) lg[e] = *(const float4*)(a.logits + row[e] * S + s0);
+      if (MODE == 0 || MODE == 3) { t1[e] = *(const float4*)(qT + (size_t)x[e] * S + s0); t2[e] = *(const float4*)(At + (size_t)x[e] * S + s0); }
+      if (MODE == 1 || MODE == 2) { t1[e] = *(const float4*)(RT + (size_t)x[e] * S + s0); t2[e] = *(const float4*)(q + (size_t)x0[e] * S + s0); }
+      if (MODE != 0) t3[e] = *(const float4*)(a.u + row[e] * S + s0);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (MODE == 0 || MODE == 3) {
+        const float l4[4] = {lg[e].x, lg[e].y, lg[e].z, lg[e].w};
+        const float mx = lwave_max(fmaxf(fmaxf(l4[0], l4[1]), fmaxf(l4[2], l4[3])));
+        float ex[4], zs = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ex[c] = expf(l4[c] - mx); zs += ex[c]; }
+        const float L = mx + logf(lwave_sum(zs));
+        float p[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = expf(l4[c] - L);
+        const float den[4] = {t1[e].x + a.eps, t1[e].y + a.eps, t1[e].z + a.eps, t1[e].w + a.eps};
+        const float at[4] = {t2[e].x, t2[e].y, t2[e].z, t2[e].w};
+        if (MODE == 0) {
+          float reg = 0.0f, nll = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { reg = fmaf(p[c], at[c], reg); nll += (s0 + c == x0[e]) ? -(l4[c] - L) : 0.0f; }
+          if (ok[e]) *(float4*)(a.grad + row[e] * S + s0) = make_float4(p[0] / den[0], p[1] / den[1], p[2] / den[2], p[3] / den[3]);
+          reg = lwave_sum(reg); nll = lwave_sum(nll);
+          if (lane == 0 && ok[e]) { double* dst = a.rows + row[e] * 4; dst[2] = reg; dst[3] = nll; }
+        } else {
+          const float dr[4] = {t3[e].x, t3[e].y, t3[e].z, t3[e].w};
+          float dp[4], pd = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { dp[c] = dr[c] / den[c] + (a.reg_scale / (float)a.B) * at[c]; pd = fmaf(p[c], dp[c], pd); }
+          pd = lwave_sum(pd);
+          float o[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = p[c] * (dp[c] - pd) + a.nll_scale * (p[c] - (s0 + c == x0[e] ? 1.0f : 0.0f));
+          if (ok[e]) *(float4*)(a.grad + row[e] * S + s0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      } else {
+        const float rt[4] = {t1[e].x, t1[e].y, t1[e].z, t1[e].w}, qx[4] = {t2[e].x, t2[e].y, t2[e].z, t2[e].w};
+        const float uu[4] = {t3[e].x, t3[e].y, t3[e].z, t3[e].w};
+        const float qx0xt = q[(size_t)x0[e] * S + x[e]] + a.eps;
+        if (MODE == 1) {
+          const float rxx = R[(size_t)x[e] * S + x[e]];
+          float outp = 0.0f, normp = 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float orate = (s0 + c == x[e]) ? 0.0f : rt[c];
+            const float Z = bsum + rxx - rdiag[c];                                    // base_sum - rs[x] + rs[s]
+            outp += orate * (qx[c] / qx0xt) * logf(uu[c] + a.eps);
+            normp += orate * qx[c] / (Z * qx0xt);
+          }
+          outp = lwave_sum(outp); normp = lwave_sum(normp);
+          if (lane == 0 && ok[e]) { double* dst = a.rows + row[e] * 4; dst[0] = outp; dst[1] = normp; }
+        } else {
+          float G[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float orate = (s0 + c == x[e]) ? 0.0f : rt[c];
+            G[c] = cb * orate * (qx[c] / qx0xt) / (uu[c] + a.eps);
+          }
+          if (ok[e]) *(float4*)(a.grad + row[e] * S + s0) = make_float4(G[0], G[1], G[2], G[3]);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace ctdd
 
 extern "C" int64_t ctdd_ctelbo_scratch_bytes(int B, int D, int S) {
@@ -612,7 +716,16 @@ extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, co
     }
     return finish_launch("k_bgemm_f32");
   };
-  if (mfma) {
+  static const bool rows8 = [] { const char* e = getenv("CTDD_ELBO_ROWS8"); return e && e[0] == '1'; }();     // (A/B: the workgroup-per-8-rows passes)
+  const bool wave_rows = mfma && S == 256 && !rows8;
+  const dim3 wg((D + 4 * RV_ROWS - 1) / (4 * RV_ROWS), B);
+  if (wave_rows) {
+    hipLaunchKernelGGL(k_elbo_rowsv<0>, wg, dim3(256), 0, st, a);               // rvec -> grad buffer; reg / nll row sums
+    if (int rc = finish_launch("k_elbo_rowsv<0>")) return rc;
+    if (int rc = gemm(a.grad, a.qT, a.u)) return rc;
+    hipLaunchKernelGGL(k_elbo_rowsv<1>, wg, dim3(256), 0, st, a);
+    if (int rc = finish_launch("k_elbo_rowsv<1>")) return rc;
+  } else if (mfma) {
     hipLaunchKernelGGL(k_elbo_fwd<1>, rg, dim3(256), 0, st, a);                 // rvec -> grad buffer; reg / nll row sums
     if (int rc = finish_launch("k_elbo_fwd<1>")) return rc;
     if (int rc = gemm(a.grad, a.qT, a.u)) return rc;                            // u[row][s] = sum_s0 rvec[row][s0] qT[s][s0]
@@ -626,6 +739,13 @@ extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, co
   if (int rc = finish_launch("k_elbo_sample_sums")) return rc;
   hipLaunchKernelGGL(k_elbo_reduce, dim3(1), dim3(256), 0, st, a, (const double*)sums);
   if (int rc = finish_launch("k_elbo_reduce")) return rc;
+  if (wave_rows) {
+    hipLaunchKernelGGL(k_elbo_rowsv<2>, wg, dim3(256), 0, st, a);               // G -> grad buffer
+    if (int rc = finish_launch("k_elbo_rowsv<2>")) return rc;
+    if (int rc = gemm(a.grad, a.q, a.u)) return rc;                             // dr = G q^T (over u)
+    hipLaunchKernelGGL(k_elbo_rowsv<3>, wg, dim3(256), 0, st, a);
+    return finish_launch("k_elbo_rowsv<3>");
+  }
   if (mfma) {
     hipLaunchKernelGGL(k_elbo_bwd<1>, rg, dim3(256), 0, st, a);                 // G -> grad buffer
     if (int rc = finish_launch("k_elbo_bwd<1>")) return rc;
