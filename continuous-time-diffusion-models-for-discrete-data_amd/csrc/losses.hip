@@ -558,6 +558,47 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(const ElboArgs a) {
       a.grad[((size_t)b * D + d0 + r) * S + t] = p[r] * (dp[r] - pdot[r]) + a.nll_scale * (p[r] - (t == x0[r] ? 1.0f : 0.0f));
 }
 
+// ---- the regulariser table on the matrix cores (S % 32 == 0): A[b][x][s0] = sum_{s != x} q[s0][s] R[s][x] / (q[s0][x] + eps)
+//   k_elbo_rt:     RT[b][x][s] = (s == x) ? 0 : R[b][s][x]      (32 x 32 tiles through LDS; + base_sum[b])
+//   k_bgemm_f32:   Atab[b][x][s0] = sum_s RT[b][x][s] q[b][s0][s]   (the zeroed diagonal: no cancellation against the -R[x][x] term)
+//   k_elbo_afix:   Atab[b][x][s0] /= qT[b][x][s0] + eps
+// (k_elbo_atab's thread-per-state fp32 FMA chains: 115 us at 64 samples.)
+__global__ __launch_bounds__(256) void k_elbo_rt(const ElboArgs a) {
+  __shared__ float tile[32][33];
+  const int S = a.S, b = blockIdx.z, x0 = blockIdx.x * 32, s0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* R = a.R + (size_t)b * S * S;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = R[(size_t)(s0 + ty + 8 * k) * S + x0 + tx];      // [s][x]
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + ty + 8 * k, s = s0 + tx;
+    a.RT[((size_t)b * S + x) * S + s] = s == x ? 0.0f : tile[tx][ty + 8 * k];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {           // base_sum[b] = sum_d rs[x~_bd]  (as k_elbo_atab)
+    const int t = threadIdx.x;
+    float sm = 0.0f;
+    for (int d = t; d < a.D; d += 256) {
+      const int x = min(max(a.xt[(size_t)b * a.D + d], 0), S - 1);
+      sm -= R[(size_t)x * S + x];
+    }
+    __shared__ float red[4];
+    sm = lwave_sum(sm);
+    if ((t & 63) == 0) red[t >> 6] = sm;
+    __syncthreads();
+    if (t == 0) a.base_sum[b] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+__global__ __launch_bounds__(256) void k_elbo_afix(const ElboArgs a) {
+  const size_t n4 = (size_t)a.B * a.S * a.S / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 v = ((const float4*)a.Atab)[i];
+    const float4 qv = ((const float4*)a.qT)[i];
+    v.x /= qv.x + a.eps; v.y /= qv.y + a.eps; v.z /= qv.z + a.eps; v.w /= qv.w + a.eps;
+    ((float4*)a.Atab)[i] = v;
+  }
+}
+
 // ---- S = 256: the four row passes around the two matrix-core GEMMs with a WAVE per row (a lane owns four consecutive states:
 // one 16-byte load per table row and lane, reductions inside the wave).  The workgroup-per-eight-rows kernels above (thread =
 // state) spend their time in block reductions -- two barriers each, six of them in a forward pass -- and the second forward
@@ -701,21 +742,33 @@ extern "C" int ctdd_ctelbo_loss_terms(const float* logits, const int32_t* x0, co
   hipStream_t st = (hipStream_t)stream;
   const dim3 rg((D + LRB - 1) / LRB, B), gg((D + 127) / 128, B);
   const bool mfma = S % 32 == 0;                     // the S x S contractions on the exact-fp32 matrix instruction
-  hipLaunchKernelGGL(k_elbo_atab, dim3((S + LRB - 1) / LRB, B), dim3(256), 0, st, a);
-  if (int rc = finish_launch("k_elbo_atab")) return rc;
-  auto gemm = [&](const float* Am, const float* Wm, float* Cm) {
+  auto gemm_m = [&](const float* Am, const float* Wm, float* Cm, int Mrows) {
+    const dim3 g2((Mrows + 127) / 128, B);
     switch (S / 32) {
-      case 1: hipLaunchKernelGGL(k_bgemm_f32<1>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      case 2: hipLaunchKernelGGL(k_bgemm_f32<2>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      case 3: hipLaunchKernelGGL(k_bgemm_f32<3>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      case 4: hipLaunchKernelGGL(k_bgemm_f32<4>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      case 5: hipLaunchKernelGGL(k_bgemm_f32<5>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      case 6: hipLaunchKernelGGL(k_bgemm_f32<6>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      case 7: hipLaunchKernelGGL(k_bgemm_f32<7>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
-      default: hipLaunchKernelGGL(k_bgemm_f32<8>, gg, dim3(256), 0, st, Am, Wm, Cm, D); break;
+      case 1: hipLaunchKernelGGL(k_bgemm_f32<1>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      case 2: hipLaunchKernelGGL(k_bgemm_f32<2>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      case 3: hipLaunchKernelGGL(k_bgemm_f32<3>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      case 4: hipLaunchKernelGGL(k_bgemm_f32<4>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      case 5: hipLaunchKernelGGL(k_bgemm_f32<5>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      case 6: hipLaunchKernelGGL(k_bgemm_f32<6>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      case 7: hipLaunchKernelGGL(k_bgemm_f32<7>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
+      default: hipLaunchKernelGGL(k_bgemm_f32<8>, g2, dim3(256), 0, st, Am, Wm, Cm, Mrows); break;
     }
     return finish_launch("k_bgemm_f32");
   };
+  auto gemm = [&](const float* Am, const float* Wm, float* Cm) { return gemm_m(Am, Wm, Cm, D); };
+  (void)gg;
+  static const bool atab_fma = [] { const char* e = getenv("CTDD_ELBO_ATAB_FMA"); return e && e[0] == '1'; }();   // (A/B: the FMA-chain table kernel)
+  if (mfma && !atab_fma) {
+    hipLaunchKernelGGL(k_elbo_rt, dim3(S / 32, S / 32, B), dim3(256), 0, st, a);
+    if (int rc = finish_launch("k_elbo_rt")) return rc;
+    if (int rc = gemm_m(a.RT, a.q, a.Atab, S)) return rc;
+    hipLaunchKernelGGL(k_elbo_afix, dim3(1024), dim3(256), 0, st, a);
+    if (int rc = finish_launch("k_elbo_afix")) return rc;
+  } else {
+    hipLaunchKernelGGL(k_elbo_atab, dim3((S + LRB - 1) / LRB, B), dim3(256), 0, st, a);
+    if (int rc = finish_launch("k_elbo_atab")) return rc;
+  }
   static const bool rows8 = [] { const char* e = getenv("CTDD_ELBO_ROWS8"); return e && e[0] == '1'; }();     // (A/B: the workgroup-per-8-rows passes)
   const bool wave_rows = mfma && S == 256 && !rows8;
   const dim3 wg((D + 4 * RV_ROWS - 1) / (4 * RV_ROWS), B);
