@@ -8,7 +8,8 @@ per feed-forward block (`AttnBlockFn`, `MlpBlockFn`: hand-scheduled backward), p
 
   linear layers      forward / data gradient (the same GEMM with the packed transposed weight): `ctdd_gemm_bf16` (bf16 operands),
                      `ctdd_unet_conv` (exact fp32);  weight gradient `ctdd_unet_wgrad` (kind 1x1: tokens are the contraction index);
-                     bias gradient `ctdd_hollow_colsum` + `ctdd_unet_sum_batch`;  operands of all weights by one
+                     bias gradient on the same launch (`ctdd_wgrad_args.gb`);  dropout / ReLU-backward masks in the GEMM epilogue
+                     (`ctdd_gemm_args.drop_p`, `mask_u`);  operands of all weights by one
                      `ctdd_unet_pack_weights` launch per forward
   LayerNorm (+FiLM)  `ctdd_hollow_layernorm` / `ctdd_hollow_layernorm_bwd` (adds the residual stream's gradient)
   attention          `ctdd_hollow_attention_train_bf16` / `_bwd_bf16` (matrix cores; dropout on the probabilities inside the

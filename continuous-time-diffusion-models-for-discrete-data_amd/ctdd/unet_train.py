@@ -311,12 +311,6 @@ class TrainCtx:
         # ---- backward plan
         bwd, bzero = [], []
         self.wgrad_entries, sum_jobs = [], []
-        ones = type("Ones", (), {})()                  # all-ones "activations" [B*H0*W0][8]: bias gradients as weight gradients
-        dt = torch.float32 if eng.precise else torch.bfloat16
-        Cin0, H0_, W0_ = eng.cfg.data.shape
-        ones_t = torch.ones((B * H0_ * W0_, 8), dtype=dt, device=dev)
-        ones.f32, ones.hi = (ones_t, None) if eng.precise else (None, ones_t)
-        self.keep.append(ones_t)
         st.cur_lists["plan"], st.cur_lists["zero"] = bwd, bzero
         # seed: gradient of the network output (logits (B, D, S) fp32 or net_out [B*HW][2C] fp32) -> the mode's operand type
         last = self.records[-1][1]
