@@ -48,42 +48,53 @@ __device__ inline unsigned short g_bf16(float v) {
 
 // KC = 32 with one chunk in flight: 128 x 128 tiles at three workgroups per CU -- best for the K = 128 layers with wide N (the A
 // tile is re-read once per 128 columns); KC = 64 with two chunks in flight on 64 x 128 tiles -- best from K = 256 up.
-template <int TM, int TN, int KC, bool DEEP>
+// SPLIT: the hi / lo split product of the inference engine, [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo] (three segments whose first
+// and third A pointers coincide), with each of its FOUR distinct operand tiles staged once per K chunk: x_hi and w_hi served two of
+// the three products from separate passes over global memory and LDS before -- a third of the loads, LDS stores and fragment reads
+// were repeats, and a barrier pair covered one product's chunk instead of all three.
+template <int TM, int TN, int KC, bool DEEP, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs a) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, LDK = KC + 8;
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDK = KC + 8, NP = SPLIT ? 2 : 1;   // NP: operand planes (hi, lo)
   constexpr int TPR = KC / 8, RPP = 256 / TPR;                  // threads per staged row piece, rows per pass
-  constexpr int AV = BM / RPP, WV = BN / RPP;                   // 16-byte vectors per thread and chunk
+  constexpr int AV = BM / RPP, WV = BN / RPP;                   // 16-byte vectors per thread, plane and chunk
   constexpr int ILD = 32 * TN + 4;                               // epilogue image row (floats)
-  constexpr int STAGE_B = 2 * (BM + BN) * LDK * 2, IMG_B = 4 * 32 * ILD * 4;
+  constexpr int STAGE_B = 2 * NP * (BM + BN) * LDK * 2, IMG_B = 4 * 32 * ILD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_B > IMG_B ? STAGE_B : IMG_B];
-  unsigned short (*As)[BM * LDK] = (unsigned short (*)[BM * LDK])smem;
-  unsigned short (*Ws)[BN * LDK] = (unsigned short (*)[BN * LDK])(smem + 2 * BM * LDK * 2);
+  unsigned short (*As)[NP * BM * LDK] = (unsigned short (*)[NP * BM * LDK])smem;                       // [buffer][plane][row][k]
+  unsigned short (*Ws)[NP * BN * LDK] = (unsigned short (*)[NP * BN * LDK])(smem + 2 * NP * BM * LDK * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int K = a.K, Ktot = a.nseg * K, cps = K / KC, nchunks = a.nseg * cps;
+  const int K = a.K, Ktot = a.nseg * K, cps = K / KC, nchunks = SPLIT ? cps : a.nseg * cps;
   const int vrow = tid / TPR, vc8 = (tid % TPR) * 8;            // staging: TPR threads per row piece of KC bf16
-  gu32x4 ra[DEEP ? 2 : 1][AV], rw[DEEP ? 2 : 1][WV];            // chunks in flight
-  auto fetch = [&](int c, gu32x4 (&pa)[AV], gu32x4 (&pw)[WV]) {
-    const int seg = c / cps, kk = (c - seg * cps) * KC;
-    const unsigned short* ap = a.a[seg];
+  gu32x4 ra[DEEP ? 2 : 1][NP * AV], rw[DEEP ? 2 : 1][NP * WV];  // chunks in flight
+  auto fetch = [&](int c, gu32x4 (&pa)[NP * AV], gu32x4 (&pw)[NP * WV]) {
+    const int seg = SPLIT ? 0 : c / cps, kk = (c - seg * cps) * KC;
 #pragma unroll
-    for (int u = 0; u < AV; ++u) {
-      const int64_t row = m0 + vrow + RPP * u;
-      pa[u] = row < a.M ? *(const gu32x4*)(ap + (size_t)row * K + kk + vc8) : gu32x4{0u, 0u, 0u, 0u};
-    }
+    for (int pl = 0; pl < NP; ++pl) {
+      const unsigned short* ap = a.a[SPLIT ? pl : seg];           // SPLIT: x_hi, x_lo
+      const int wcol = SPLIT ? 2 * pl * K : seg * K;              // SPLIT: w_hi at columns [0, K), w_lo at [2K, 3K) of the packed rows
 #pragma unroll
-    for (int u = 0; u < WV; ++u) {
-      const int n = n0 + vrow + RPP * u;
-      pw[u] = n < a.N ? *(const gu32x4*)(a.w + (size_t)n * Ktot + seg * K + kk + vc8) : gu32x4{0u, 0u, 0u, 0u};
+      for (int u = 0; u < AV; ++u) {
+        const int64_t row = m0 + vrow + RPP * u;
+        pa[pl * AV + u] = row < a.M ? *(const gu32x4*)(ap + (size_t)row * K + kk + vc8) : gu32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < WV; ++u) {
+        const int n = n0 + vrow + RPP * u;
+        pw[pl * WV + u] = n < a.N ? *(const gu32x4*)(a.w + (size_t)n * Ktot + wcol + kk + vc8) : gu32x4{0u, 0u, 0u, 0u};
+      }
     }
   };
-  auto stash = [&](int buf, const gu32x4 (&pa)[AV], const gu32x4 (&pw)[WV]) {
+  auto stash = [&](int buf, const gu32x4 (&pa)[NP * AV], const gu32x4 (&pw)[NP * WV]) {
 #pragma unroll
-    for (int u = 0; u < AV; ++u) *(gu32x4*)(&As[buf][(vrow + RPP * u) * LDK + vc8]) = pa[u];
+    for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-    for (int u = 0; u < WV; ++u) *(gu32x4*)(&Ws[buf][(vrow + RPP * u) * LDK + vc8]) = pw[u];
+      for (int u = 0; u < AV; ++u) *(gu32x4*)(&As[buf][pl * BM * LDK + (vrow + RPP * u) * LDK + vc8]) = pa[pl * AV + u];
+#pragma unroll
+      for (int u = 0; u < WV; ++u) *(gu32x4*)(&Ws[buf][pl * BN * LDK + (vrow + RPP * u) * LDK + vc8]) = pw[pl * WV + u];
+    }
   };
   gf32x16 acc[TM][TN];
 #pragma unroll
@@ -97,15 +108,24 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs a) {
     const unsigned short* Wb = &Ws[buf][(wn * 32 * TN + li) * LDK + 8 * kh];
 #pragma unroll
     for (int s_ = 0; s_ < KC / 16; ++s_) {
-      gbf16x8 af[TM], bf[TN];
+      gbf16x8 af[NP][TM], bf[NP][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const gbf16x8*)(Ab + (size_t)i * 32 * LDK + 16 * s_);
+      for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *(const gbf16x8*)(Wb + (size_t)j * 32 * LDK + 16 * s_);
+        for (int i = 0; i < TM; ++i) af[pl][i] = *(const gbf16x8*)(Ab + (size_t)pl * BM * LDK + (size_t)i * 32 * LDK + 16 * s_);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[pl][j] = *(const gbf16x8*)(Wb + (size_t)pl * BN * LDK + (size_t)j * 32 * LDK + 16 * s_);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+          if constexpr (SPLIT) {                                 // + x_lo w_hi + x_hi w_lo  (x_lo w_lo ~ 2^-17 of the product: dropped)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+          }
+        }
     }
   };
   // chunk c lives in registers set c & 1 until it is stashed into LDS buffer c & 1; chunk c + 2 is requested before chunk c is
@@ -207,6 +227,16 @@ extern "C" int ctdd_gemm_bf16(const void* args_, void* stream) {
   //   K' <= 256, wider N     64 x 128 tiles, chunks of 32                           (fc1 / du 31.1 vs 36.2)
   //   K' >= 512              128 x 128 tiles, two chunks of 64 (32) in flight       (the hi / lo split products: 450-500 TFLOP/s)
   // The two-in-flight loop needs an even chunk count: K % 64 == 0 makes it so at chunks of 32, at 64 only for even nseg K / 64.
+  static const bool no_split = [] { const char* e = getenv("CTDD_GEMM_NO_SPLIT"); return e && e[0] == '1'; }();    // (A/B: three separate segments)
+  if (!no_split && a.nseg == 3 && a.a[0] == a.a[2] && a.a[0] != a.a[1] && a.N > 64) {
+    // the hi / lo split product: four operand tiles per K chunk instead of six (k_gemm_bf16<..., SPLIT>); K % 64 == 0 makes
+    // the chunk count of 32-wide chunks even, as the two-in-flight loop needs
+    // (64 x 128 tiles, two workgroups per CU, for K <= 128 -- four chunks: the maze sampler 12.97 -> 13.19 k sample-steps/s; 128 x 128
+    //  from K = 256 up: the MNIST hollow sampler 4.34 -> 4.59 k)
+    if (a.N <= 128 || a.K <= 128) hipLaunchKernelGGL((k_gemm_bf16<1, 2, 32, true, true>), dim3((unsigned)((a.M + 63) / 64), (a.N + 127) / 128), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gemm_bf16<2, 2, 32, true, true>), dim3((unsigned)((a.M + 127) / 128), (a.N + 127) / 128), dim3(256), 0, st, a);
+    return finish_launch("k_gemm_bf16<split>");
+  }
   const int Kt = a.nseg * a.K;
   const bool even64 = (Kt / 64) % 2 == 0;
   const dim3 g11((unsigned)((a.M + 63) / 64), (a.N + 63) / 64), g12((unsigned)((a.M + 63) / 64), (a.N + 127) / 128),

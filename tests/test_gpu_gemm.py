@@ -112,3 +112,30 @@ def test_gemm_training_epilogues_match_the_separate_passes(M, K, N):
     got = gemm(None, True, mask=u)
     ref = torch.where(u != 0, gemm(None, False) / (1.0 - p), torch.zeros((), device="cuda"))
     assert torch.allclose(got, ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("M,K,N", [(700, 128, 384), (513, 256, 1024), (300, 1024, 256), (257, 128, 128), (640, 256, 72)])
+def test_gemm_split_product_kernel(M, K, N):
+    """The hi / lo split product [x_hi | x_lo | x_hi] . [w_hi | w_hi | w_lo] (first and third segment the same tensor): the launcher
+    stages its four distinct operand tiles once per K chunk (k_gemm_bf16<..., SPLIT>); N <= 64 keeps the three-segment kernel.
+    Against x_hi w_hi + x_lo w_hi + x_hi w_lo in float64, and: the result is within 2^-15 of the fp32 product of the unsplit operands."""
+    from ctdd import hollow_train as ht
+    from ctdd.hollow_engine import _GemmArgs
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    xh = x.to(torch.bfloat16); xl = (x - xh.float()).to(torch.bfloat16)
+    wh = w.to(torch.bfloat16); wl = (w - wh.float()).to(torch.bfloat16)
+    wcat = torch.cat([wh, wh, wl], dim=1).contiguous()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    a = _GemmArgs()
+    a.a[0], a.a[1], a.a[2] = xh.data_ptr(), xl.data_ptr(), xh.data_ptr()
+    a.nseg, a.w, a.bias, a.out_f32, a.M, a.N, a.K = 3, wcat.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K
+    ht._ck(ht.lib().ctdd_gemm_bf16(C.byref(a), torch.cuda.current_stream().cuda_stream), "ctdd_gemm_bf16")
+    ref = (xh.double() @ wh.double().t() + xl.double() @ wh.double().t() + xh.double() @ wl.double().t() + b.double())
+    assert torch.isfinite(out).all()
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 2e-6 * scale * K ** 0.5
+    full = x.double() @ w.double().t() + b.double()
+    assert float((out.double() - full).abs().max()) < 2.0 ** -15 * scale * 4
