@@ -2023,6 +2023,93 @@ __global__ __launch_bounds__(256) void k_attn_small(const AttnArgs a) {
   }
 }
 
+// The same with 4 x 4 register tiles: both products were LDS-bound with two 4-byte reads per multiply-add -- and the k rows of
+// the score product, read at a stride of ch floats by neighbouring lanes, all fell into one bank (ch = 192 = 3 x 64: a 64-way
+// conflict): 46 us per 128 samples at 7x7, C = 192.  Here q and k sit TRANSPOSED in LDS ([channel][token], rows padded to a
+// multiple of four tokens), a thread owns a 4-token x 4-token block of the scores (one 16-byte read of each operand per 16
+// multiply-adds, neighbouring lanes read neighbouring pieces), the scores are kept token-major-transposed (wT[s][t]) so that the
+// output product reads them the same way against 16-byte pieces of v.  Same summation orders as k_attn_small (c ascending, s ascending,
+// the 4-lane softmax split): identical results.
+__global__ __launch_bounds__(256) void k_attn_small_t4(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x / a.heads, hd = blockIdx.x % a.heads, ch = a.C / a.heads, T = a.T, Tp = (T + 3) & ~3;
+  float* qT = sm; float* kT = qT + ch * Tp; float* v = kT + ch * Tp; float* wT = v + T * ch; float* rz = wT + T * Tp;
+  const float sc = 1.0f / sqrtf(sqrtf((float)ch));
+  for (int i = threadIdx.x; i < ch * (Tp - T); i += 256) {            // pad tokens: zeros (their score columns are never used)
+    const int c = i / (Tp - T), t = T + i % (Tp - T);
+    qT[c * Tp + t] = 0.0f; kT[c * Tp + t] = 0.0f;
+  }
+  for (int i = threadIdx.x; i < T * ch; i += 256) {
+    const int t = i / ch, c = i % ch;
+    const float* src = a.qkv + ((size_t)b * T + t) * 3 * a.C + hd * 3 * ch;
+    qT[c * Tp + t] = src[c] * sc; kT[c * Tp + t] = src[ch + c] * sc; v[i] = src[2 * ch + c];
+  }
+  __syncthreads();
+  const int nbt = Tp / 4;
+  for (int blk = threadIdx.x; blk < nbt * nbt; blk += 256) {
+    const int tb = blk / nbt, sb = blk % nbt;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    for (int c = 0; c < ch; ++c) {
+      const float4 qa = *(const float4*)(qT + c * Tp + 4 * tb), kb = *(const float4*)(kT + c * Tp + 4 * sb);
+      const float qv[4] = {qa.x, qa.y, qa.z, qa.w}, kv[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(qv[i], kv[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * sb + j < T) *(float4*)(wT + (4 * sb + j) * Tp + 4 * tb) = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+  }
+  __syncthreads();
+  for (int t4 = threadIdx.x; t4 < ((T + 63) / 64) * 256; t4 += 256) {          // softmax over s for token t: four lanes per token
+    const int t = t4 >> 2, l4 = t4 & 3;
+    float m = -INFINITY;
+    if (t < T)
+      for (int s_ = l4; s_ < T; s_ += 4) m = fmaxf(m, wT[s_ * Tp + t]);
+    m = fmaxf(m, __shfl_xor(m, 1, WAVE));
+    m = fmaxf(m, __shfl_xor(m, 2, WAVE));
+    float z = 0.0f;
+    if (t < T)
+      for (int s_ = l4; s_ < T; s_ += 4) { const float e = expf(wT[s_ * Tp + t] - m); wT[s_ * Tp + t] = e; z += e; }
+    z += __shfl_xor(z, 1, WAVE);
+    z += __shfl_xor(z, 2, WAVE);
+    if (t < T && l4 == 0) rz[t] = 1.0f / z;
+  }
+  __syncthreads();
+  const int nbc = ch / 4;
+  for (int blk = threadIdx.x; blk < nbt * nbc; blk += 256) {
+    const int tb = blk / nbc, cb = blk % nbc;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    for (int s_ = 0; s_ < T; ++s_) {
+      const float4 wa = *(const float4*)(wT + s_ * Tp + 4 * tb), vb = *(const float4*)(v + s_ * ch + 4 * cb);
+      const float wv[4] = {wa.x, wa.y, wa.z, wa.w}, vv[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(wv[i], vv[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = 4 * tb + i;
+      if (t >= T) break;
+      const float r = rz[t];
+      const float o0 = acc[i][0] * r, o1 = acc[i][1] * r, o2 = acc[i][2] * r, o3 = acc[i][3] * r;
+      const size_t oo = ((size_t)b * T + t) * a.C + hd * ch + 4 * cb;
+      if (a.out_hi) *(uint2*)(a.out_hi + oo) = make_uint2((unsigned)to_bf16(o0) | ((unsigned)to_bf16(o1) << 16), (unsigned)to_bf16(o2) | ((unsigned)to_bf16(o3) << 16));
+      if (a.out_f32) *(float4*)(a.out_f32 + oo) = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ logistic head (models.py:249-283)
 // mu = tanh(loc + x0), logits[s] = log(sigmoid(r) - sigmoid(l)) via log_minus_exp, straight into (B,D,S)
 struct LogisticArgs { const float* net; const float* x0; int B, C, HW, S, fix; float* out; int fast; };
@@ -2393,6 +2480,17 @@ extern "C" int ctdd_unet_time_uniform(const void* args_, const float* proj_w, co
 extern "C" int ctdd_unet_attention(const void* args_, void* stream) {
   const AttnArgs& a = *(const AttnArgs*)args_;
   const int ch = a.C / a.heads;
+  {
+    const int Tp = (a.T + 3) & ~3;
+    const size_t lds4 = (size_t)(2 * ch * Tp + a.T * ch + a.T * Tp + a.T) * sizeof(float);
+    static const bool old_attn = [] { const char* e = getenv("CTDD_ATTN_SMALL_OLD"); return e && e[0] == '1'; }();    // (A/B)
+    if (!old_attn && ch % 4 == 0 && a.C % 4 == 0 && lds4 <= 160 * 1024) {
+      static bool done[16] = {};
+      ensure_lds_ceiling((const void*)k_attn_small_t4, done);
+      hipLaunchKernelGGL(k_attn_small_t4, dim3(a.B * a.heads), dim3(256), lds4, (hipStream_t)stream, a);
+      return finish_launch("k_attn_small_t4");
+    }
+  }
   const size_t lds = (size_t)(3 * a.T * ch + a.T * a.T + a.T) * sizeof(float);
   CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "attention tile too large (T=%d)", a.T);
   if (lds > 48 * 1024)
