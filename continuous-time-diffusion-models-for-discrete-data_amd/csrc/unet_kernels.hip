@@ -1746,8 +1746,10 @@ __global__ __launch_bounds__(1024) void k_gn_onepass(const GnArgs a, int slabC, 
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   const int C = a.C1 + a.C2, cg = C / a.G, b = blockIdx.y, cs0 = blockIdx.x * slabC, HW = a.HW;
   const int t = threadIdx.x, T = noct * npl;
-  float* part = (float*)gsm;                                   // [T][16]: sums, sums of squares of the thread's 8 channels
-  double* red = (double*)(gsm + (size_t)T * 64);               // [2][slabC]
+  constexpr int PST = 20;                                      // floats per thread record: 16 used; 80-byte records put the 16-byte stores
+                                                               // of 16 neighbouring threads on all 64 banks (64-byte records: 16-way conflicts)
+  float* part = (float*)gsm;                                   // [T][PST]: sums, sums of squares of the thread's 8 channels
+  double* red = (double*)(gsm + (size_t)T * PST * 4);          // [2][slabC]
   float* scale = (float*)(red + 2 * slabC);                    // [slabC]
   float* shift = scale + slabC;
   const bool act = t < T;
@@ -1776,16 +1778,16 @@ __global__ __launch_bounds__(1024) void k_gn_onepass(const GnArgs a, int slabC, 
     }
   }
   if (act) {
-    float4* pt = (float4*)(part + (size_t)t * 16);
+    float4* pt = (float4*)(part + (size_t)t * PST);
     pt[0] = make_float4(sx[0], sx[1], sx[2], sx[3]); pt[1] = make_float4(sx[4], sx[5], sx[6], sx[7]);
     pt[2] = make_float4(sq[0], sq[1], sq[2], sq[3]); pt[3] = make_float4(sq[4], sq[5], sq[6], sq[7]);
   }
   __syncthreads();
   for (int r = t; r < 2 * slabC; r += blockDim.x) {            // (moment m, local channel cl): over the pixel lanes, in fp64
     const int m = r / slabC, cl = r - m * slabC;
-    const float* pp = part + (size_t)(cl >> 3) * 16 + m * 8 + (cl & 7);
+    const float* pp = part + (size_t)(cl >> 3) * PST + m * 8 + (cl & 7);
     double acc = 0.0;
-    for (int q = 0; q < npl; ++q) acc += (double)pp[(size_t)q * noct * 16];
+    for (int q = 0; q < npl; ++q) acc += (double)pp[(size_t)q * noct * PST];
     red[r] = acc;
     // training plans: the per-(sample, channel) sums also go to the sources' statistics buffers (what the producers'
     // epilogues would have accumulated), for the GroupNorm backward
@@ -2426,7 +2428,7 @@ extern "C" int ctdd_unet_gn_onepass(const void* args_, int slabC, int max_thread
   const int need = 2 * slabC;                                    // the reduction wants a thread per (moment, channel) at best
   if (threads < 256) threads = 256;
   (void)need;
-  const size_t lds = (size_t)noct * npl * 64 + (size_t)2 * slabC * 8 + (size_t)2 * slabC * 4;
+  const size_t lds = (size_t)noct * npl * 80 + (size_t)2 * slabC * 8 + (size_t)2 * slabC * 4;     // (80-byte thread records: k_gn_onepass PST)
   const dim3 g((unsigned)(C / slabC), (unsigned)a.B);
   hipStream_t st = (hipStream_t)stream;
   static bool attr_done[4][16] = {};
