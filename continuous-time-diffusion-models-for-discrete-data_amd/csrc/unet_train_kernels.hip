@@ -635,8 +635,10 @@ __global__ __launch_bounds__(512) void k_gn_bwd_onepass(const GnBwdArgs a, int s
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   const int C = a.C1 + a.C2, cg = C / a.G, b = blockIdx.x, cs0 = blockIdx.y * slabC, HW = a.HW;
   const int t = threadIdx.x, T = noct * npl;
-  float* part = (float*)gsm;                                   // [T][16]
-  float* tab = part + (size_t)T * 16;                          // mean, rstd, gamma, beta, S1, S2, m1, m2: [8][slabC]
+  constexpr int PST = 20;                                      // floats per thread record (16 used): 80-byte records spread the 16-byte
+                                                               // stores of neighbouring threads over all banks (as k_gn_onepass)
+  float* part = (float*)gsm;                                   // [T][PST]
+  float* tab = part + (size_t)T * PST;                         // mean, rstd, gamma, beta, S1, S2, m1, m2: [8][slabC]
   const bool act = t < T;
   const int oct = act ? t % noct : 0, pl = act ? t / noct : 0;
   const int c0 = cs0 + oct * 8;
@@ -699,16 +701,16 @@ __global__ __launch_bounds__(512) void k_gn_bwd_onepass(const GnBwdArgs a, int s
     }
   }
   if (act) {
-    float4* pt = (float4*)(part + (size_t)t * 16);
+    float4* pt = (float4*)(part + (size_t)t * PST);
     pt[0] = make_float4(s1[0], s1[1], s1[2], s1[3]); pt[1] = make_float4(s1[4], s1[5], s1[6], s1[7]);
     pt[2] = make_float4(s2[0], s2[1], s2[2], s2[3]); pt[3] = make_float4(s2[4], s2[5], s2[6], s2[7]);
   }
   __syncthreads();
   for (int r = t; r < 2 * slabC; r += blockDim.x) {
     const int which = r / slabC, cl = r - which * slabC;
-    const float* pp = part + (size_t)(cl >> 3) * 16 + which * 8 + (cl & 7);
+    const float* pp = part + (size_t)(cl >> 3) * PST + which * 8 + (cl & 7);
     float acc = 0.0f;
-    for (int q = 0; q < npl; ++q) acc += pp[(size_t)q * noct * 16];
+    for (int q = 0; q < npl; ++q) acc += pp[(size_t)q * noct * PST];
     tab[(4 + which) * slabC + cl] = acc;
     a.sums[((size_t)b * C + cs0 + cl) * 2 + which] = acc;      // (sole owner of these entries: no atomics)
   }
@@ -1177,7 +1179,7 @@ extern "C" int ctdd_unet_gn_bwd(const void* args_, void* stream) {
     }
     if (best > 0) {
       const int threads = max(64, ((bo * bp + 63) / 64) * 64);
-      const size_t lds = (size_t)bo * bp * 64 + (size_t)8 * best * sizeof(float);
+      const size_t lds = (size_t)bo * bp * 80 + (size_t)8 * best * sizeof(float);      // (80-byte thread records: PST)
       const dim3 g((unsigned)a.B, (unsigned)(C / best));
       static bool attr_done[3][16] = {};
       auto go = [&](auto kernel, int slot) {
