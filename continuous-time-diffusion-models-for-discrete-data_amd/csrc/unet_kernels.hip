@@ -1647,6 +1647,50 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnArgs a) {
   if (!a.s1_f32 && !a.out_f32 && nv < (int64_t)1 << 30) {
     // bf16 in / bf16 out (the throughput mode): four 16-byte vectors in flight per thread, 32-bit index arithmetic
     const unsigned n32 = (unsigned)nv, stride = gridDim.x * 256u, uvpp = (unsigned)vpp;
+    if (stride % uvpp == 0u) {
+      // the launcher made the thread stride a multiple of the vectors per pixel: a thread's vectors are all the SAME eight channels --
+      // scale / shift sit in registers (they were four 16-byte LDS reads per vector, with 2-way bank conflicts), the source and the
+      // channel offset are fixed, a step is a whole number of pixels
+      using f2 = __attribute__((ext_vector_type(2))) float;
+      const unsigned vfirst = blockIdx.x * 256u + threadIdx.x, px0 = vfirst / uvpp, c0 = (vfirst - px0 * uvpp) * 8u, pstep = stride / uvpp;
+      const bool first = (int)c0 < a.C1;
+      const unsigned Cs = first ? (unsigned)a.C1 : (unsigned)a.C2, cc = first ? c0 : c0 - (unsigned)a.C1;
+      const unsigned short* src = (first ? a.s1_bf16 : a.s2_bf16) + (size_t)b * a.HW * Cs + cc;
+      unsigned short* dst = a.out_hi + (size_t)b * a.HW * C + c0;
+      const float4 sc0 = *(const float4*)(scale + c0), sc1 = *(const float4*)(scale + c0 + 4);
+      const float4 sh0 = *(const float4*)(shift + c0), sh1 = *(const float4*)(shift + c0 + 4);
+      const f2 scv[4] = {{sc0.x, sc0.y}, {sc0.z, sc0.w}, {sc1.x, sc1.y}, {sc1.z, sc1.w}};
+      const f2 shv[4] = {{sh0.x, sh0.y}, {sh0.z, sh0.w}, {sh1.x, sh1.y}, {sh1.z, sh1.w}};
+      const unsigned HWu = (unsigned)a.HW;
+      for (unsigned px = px0; px < HWu; px += 4u * pstep) {
+        uint4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned pk = px + (unsigned)k * pstep;
+          u[k] = pk < HWu ? *(const uint4*)(src + (size_t)pk * Cs) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned pk = px + (unsigned)k * pstep;
+          if (pk >= HWu) break;
+          const unsigned w[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+          unsigned ow[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f2 x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+            f2 y = __builtin_elementwise_fma(x, scv[j], shv[j]);
+            if (a.swish) {
+              const f2 z = y * (f2){-1.4426950408889634f, -1.4426950408889634f};
+              const f2 d = (f2){__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + (f2){1.0f, 1.0f};
+              y = y * (f2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            }
+            ow[j] = pack2_bf16(y.x, y.y);
+          }
+          *(uint4*)(dst + (size_t)pk * C) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+      }
+      return;
+    }
     for (unsigned v0 = blockIdx.x * 256u + threadIdx.x; v0 < n32; v0 += 4u * stride) {
       uint4 u[4];
       unsigned c0[4];
@@ -2385,6 +2429,16 @@ extern "C" int ctdd_unet_gn_apply(const void* args_, void* stream) {
   int gx = (int)((nv + 2047) / 2048);      // >= 8 vectors per thread: the per-workgroup scale/shift prologue (fp64 divide + sqrt) stays small
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
+  {
+    // a thread stride (gx * 256 vectors) that is a multiple of the C / 8 vectors per pixel lets a thread keep its channels' scale /
+    // shift in registers (k_gn_apply's bf16 path): round gx up to the next such count when that costs at most half again as many
+    // workgroups
+    const int vpp = C / 8;
+    int g = vpp, r = 256;
+    while (r) { const int t = g % r; g = r; r = t; }                 // gcd(vpp, 256)
+    const int unit = vpp / g, gu = ((gx + unit - 1) / unit) * unit;
+    if (gu <= gx + (gx + 1) / 2 + 1 && gu <= 96) gx = gu;
+  }
   hipLaunchKernelGGL(k_gn_apply, dim3(gx, a.B), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream, a);
   return finish_launch("k_gn_apply");
 }
