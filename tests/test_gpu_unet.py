@@ -410,9 +410,18 @@ def test_gn_onepass_matches_groupnorm(B, H, C1, C2, G, swish, slab):
     if C2:
         a.s2_bf16, a.C2 = srcs[1].data_ptr(), C2
     a.gamma, a.beta, a.B, a.HW, a.G, a.eps, a.swish, a.out_hi = gamma.data_ptr(), beta.data_ptr(), B, HW, G, 1e-5, swish, out.data_ptr()
+    # training plans hand the kernel the sources' statistics buffers: it leaves the per-(sample, channel) sums / sums of squares there
+    stats = [torch.full((B, c, 2), float("nan"), dtype=torch.float64, device="cuda") for c in (C1, C2) if c]
+    a.st1 = stats[0].data_ptr()
+    if C2:
+        a.st2 = stats[1].data_ptr()
     rc = lib.ctdd_unet_gn_onepass(C_.byref(a), slab, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.ctdd_last_error().decode()
     assert ue._onepass_slab(B, HW, Ct, G) > 0
+    for s_, st_ in zip(srcs, stats):
+        xs = s_.double()
+        ref_st = torch.stack([xs.sum(1), (xs * xs).sum(1)], dim=2)                # (B, c, 2)
+        assert torch.allclose(st_, ref_st, rtol=2e-5, atol=1e-3), float((st_ - ref_st).abs().max())
     x = torch.cat([s_.float() for s_ in srcs], 2).permute(0, 2, 1).reshape(B, Ct, H, H)
     want = torch.nn.functional.group_norm(x, G, gamma, beta, 1e-5)
     if swish:
