@@ -478,3 +478,27 @@ def test_engine_onepass_groupnorm_plans_match_statistics_epilogue_plans():
     for flag in (1, 0):
         assert float((outs[flag] - want).abs().max()) < 5e-2 * scale
     assert float((outs[1] - outs[0]).abs().max()) < 2e-2 * scale
+
+
+@pytest.mark.parametrize("B,T,C,heads", [(5, 49, 192, 1), (3, 49, 192, 8), (2, 16, 64, 4), (2, 64, 32, 1), (3, 50, 96, 2)])
+def test_mid_attention_kernel(B, T, C, heads):
+    """ctdd_unet_attention (k_attn_small_t4: transposed q / k in LDS, 4 x 4 register tiles; token counts that are not multiples of
+    four pad the tiles) against the reference's QKVAttention in torch (unet.py:176-200: per-head channel order [q | k | v], both q
+    and k scaled by ch^-1/4, softmax over the keys)."""
+    import ctypes as C_
+    from ctdd import unet_engine as ue
+    lib = ue._lib()
+    g = torch.Generator(device="cuda").manual_seed(T * 100 + C + heads)
+    qkv = torch.randn((B, T, 3 * C), device="cuda", generator=g)
+    out = torch.full((B * T, C), float("nan"), device="cuda")
+    a = ue._AttnArgs()
+    a.qkv, a.B, a.T, a.C, a.heads, a.out_f32 = qkv.data_ptr(), B, T, C, heads, out.data_ptr()
+    assert lib.ctdd_unet_attention(C_.byref(a), torch.cuda.current_stream().cuda_stream) == 0, lib.ctdd_last_error().decode()
+    ch = C // heads
+    x = qkv.view(B, T, heads, 3, ch).permute(0, 2, 3, 1, 4)              # (B, heads, 3, T, ch)
+    q, k, v = x[:, :, 0], x[:, :, 1], x[:, :, 2]
+    sc = ch ** -0.25
+    w = torch.softmax(torch.einsum("bhtc,bhsc->bhts", q * sc, k * sc), dim=-1)
+    ref = torch.einsum("bhts,bhsc->bhtc", w, v).permute(0, 2, 1, 3).reshape(B * T, C)
+    assert torch.isfinite(out).all()
+    assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-6
