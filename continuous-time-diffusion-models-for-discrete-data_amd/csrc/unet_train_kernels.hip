@@ -962,6 +962,121 @@ __global__ __launch_bounds__(256) void k_attn_small_bwd(const AttnBwdArgs a) {
   }
 }
 
+// The same on 4 x 4 register tiles (as k_attn_small_t4 of the forward): q, k, v, dO TRANSPOSED in LDS for the two token x token
+// products (scores and dW), row-major for the three token x channel products, dS kept in both orientations -- one 16-byte read per
+// operand and 16 (32, 48) multiply-adds; the thread-per-score kernel above read k and v rows at a stride of ch floats across
+// neighbouring lanes (bank conflicts: 58 % of its LDS cycles) and ran the softmax rows on T of its 256 threads.
+__global__ __launch_bounds__(256) void k_attn_small_bwd_t4(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x / a.heads, hd = blockIdx.x % a.heads, ch = a.C / a.heads, T = a.T, Tp = (T + 3) & ~3;
+  float* qT = sm; float* kT = qT + ch * Tp; float* vT = kT + ch * Tp; float* dOT = vT + ch * Tp;      // [ch][Tp]
+  float* q = dOT + ch * Tp; float* k = q + T * ch; float* dO = k + T * ch;                             // [T][ch]
+  float* w = dO + T * ch; float* dS = w + T * Tp; float* dST = dS + T * Tp;                            // [T][Tp]
+  const float sc = 1.0f / sqrtf(sqrtf((float)ch));
+  for (int i = threadIdx.x; i < 4 * ch * Tp + 3 * T * ch + 3 * T * Tp; i += 256) sm[i] = 0.0f;        // (pad tokens: zeros everywhere)
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * ch; i += 256) {
+    const int t = i / ch, c = i % ch;
+    const float* src = a.qkv + ((size_t)b * T + t) * 3 * a.C + hd * 3 * ch;
+    const float qv = src[c] * sc, kv = src[ch + c] * sc, vv = src[2 * ch + c];
+    const size_t oo = ((size_t)b * T + t) * a.C + hd * ch + c;
+    const float dv_ = a.d_out_f32 ? a.d_out_f32[oo] : bf_lo((unsigned)a.d_out_bf16[oo]);
+    q[i] = qv; k[i] = kv; dO[i] = dv_;
+    qT[c * Tp + t] = qv; kT[c * Tp + t] = kv; vT[c * Tp + t] = vv; dOT[c * Tp + t] = dv_;
+  }
+  __syncthreads();
+  const int nbt = Tp / 4;
+  for (int blk = threadIdx.x; blk < nbt * nbt; blk += 256) {          // scores w[t][s] and dW[t][s] (into dS)
+    const int tb = blk / nbt, sb = blk % nbt;
+    float aw[4][4], ad[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { aw[i][j] = 0.0f; ad[i][j] = 0.0f; }
+    for (int c = 0; c < ch; ++c) {
+      const float4 qa = *(const float4*)(qT + c * Tp + 4 * tb), kb = *(const float4*)(kT + c * Tp + 4 * sb);
+      const float4 da = *(const float4*)(dOT + c * Tp + 4 * tb), vb = *(const float4*)(vT + c * Tp + 4 * sb);
+      const float qv[4] = {qa.x, qa.y, qa.z, qa.w}, kv[4] = {kb.x, kb.y, kb.z, kb.w}, dv_[4] = {da.x, da.y, da.z, da.w}, vv[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { aw[i][j] = fmaf(qv[i], kv[j], aw[i][j]); ad[i][j] = fmaf(dv_[i], vv[j], ad[i][j]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * tb + i < T) {
+        *(float4*)(w + (4 * tb + i) * Tp + 4 * sb) = make_float4(aw[i][0], aw[i][1], aw[i][2], aw[i][3]);
+        *(float4*)(dS + (4 * tb + i) * Tp + 4 * sb) = make_float4(ad[i][0], ad[i][1], ad[i][2], ad[i][3]);
+      }
+  }
+  __syncthreads();
+  for (int t4 = threadIdx.x; t4 < ((T + 63) / 64) * 256; t4 += 256) {  // softmax rows and dS = w (dW - sum_s dW w): four lanes per row
+    const int t = t4 >> 2, l4 = t4 & 3;
+    float m = -INFINITY;
+    if (t < T)
+      for (int s_ = l4; s_ < T; s_ += 4) m = fmaxf(m, w[t * Tp + s_]);
+    m = fmaxf(m, __shfl_xor(m, 1, WAVE));
+    m = fmaxf(m, __shfl_xor(m, 2, WAVE));
+    float z = 0.0f;
+    if (t < T)
+      for (int s_ = l4; s_ < T; s_ += 4) { const float e = expf(w[t * Tp + s_] - m); w[t * Tp + s_] = e; z += e; }
+    z += __shfl_xor(z, 1, WAVE);
+    z += __shfl_xor(z, 2, WAVE);
+    const float iz = 1.0f / z;
+    float dot = 0.0f;
+    if (t < T)
+      for (int s_ = l4; s_ < T; s_ += 4) { const float p = w[t * Tp + s_] * iz; w[t * Tp + s_] = p; dot = fmaf(dS[t * Tp + s_], p, dot); }
+    dot += __shfl_xor(dot, 1, WAVE);
+    dot += __shfl_xor(dot, 2, WAVE);
+    if (t < T)
+      for (int s_ = l4; s_ < T; s_ += 4) {
+        const float v_ = w[t * Tp + s_] * (dS[t * Tp + s_] - dot);
+        dS[t * Tp + s_] = v_;
+        dST[s_ * Tp + t] = v_;
+      }
+  }
+  __syncthreads();
+  const int nbc = ch / 4;
+  for (int blk = threadIdx.x; blk < nbt * nbc; blk += 256) {          // dq, dk, dv for a block of 4 tokens x 4 channels
+    const int tb = blk / nbc, cb = blk % nbc;
+    float aq[4][4], ak[4][4], av[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { aq[i][j] = 0.0f; ak[i][j] = 0.0f; av[i][j] = 0.0f; }
+    for (int s_ = 0; s_ < T; ++s_) {
+      const float4 d1 = *(const float4*)(dST + s_ * Tp + 4 * tb);      // dS[t0..t0+3][s]
+      const float4 d2 = *(const float4*)(dS + s_ * Tp + 4 * tb);       // dS[s][t0..t0+3]
+      const float4 w2 = *(const float4*)(w + s_ * Tp + 4 * tb);        // w[s][t0..t0+3]
+      const float4 kb = *(const float4*)(k + s_ * ch + 4 * cb), qb = *(const float4*)(q + s_ * ch + 4 * cb), ob = *(const float4*)(dO + s_ * ch + 4 * cb);
+      const float x1[4] = {d1.x, d1.y, d1.z, d1.w}, x2[4] = {d2.x, d2.y, d2.z, d2.w}, x3[4] = {w2.x, w2.y, w2.z, w2.w};
+      const float y1[4] = {kb.x, kb.y, kb.z, kb.w}, y2[4] = {qb.x, qb.y, qb.z, qb.w}, y3[4] = {ob.x, ob.y, ob.z, ob.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          aq[i][j] = fmaf(x1[i], y1[j], aq[i][j]); ak[i][j] = fmaf(x2[i], y2[j], ak[i][j]); av[i][j] = fmaf(x3[i], y3[j], av[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = 4 * tb + i;
+      if (t >= T) break;
+      const size_t d0 = ((size_t)b * T + t) * 3 * a.C + hd * 3 * ch + 4 * cb;
+      if (a.d_qkv) {
+        *(float4*)(a.d_qkv + d0) = make_float4(aq[i][0] * sc, aq[i][1] * sc, aq[i][2] * sc, aq[i][3] * sc);
+        *(float4*)(a.d_qkv + d0 + ch) = make_float4(ak[i][0] * sc, ak[i][1] * sc, ak[i][2] * sc, ak[i][3] * sc);
+        *(float4*)(a.d_qkv + d0 + 2 * ch) = make_float4(av[i][0], av[i][1], av[i][2], av[i][3]);
+      }
+      if (a.d_qkv_bf16) {
+        *(uint2*)(a.d_qkv_bf16 + d0) = make_uint2(pack2_bf16(aq[i][0] * sc, aq[i][1] * sc), pack2_bf16(aq[i][2] * sc, aq[i][3] * sc));
+        *(uint2*)(a.d_qkv_bf16 + d0 + ch) = make_uint2(pack2_bf16(ak[i][0] * sc, ak[i][1] * sc), pack2_bf16(ak[i][2] * sc, ak[i][3] * sc));
+        *(uint2*)(a.d_qkv_bf16 + d0 + 2 * ch) = make_uint2(pack2_bf16(av[i][0], av[i][1]), pack2_bf16(av[i][2], av[i][3]));
+      }
+    }
+  }
+}
+
 // ============================================================================ first conv weight gradient (unet.py:343, C_in = 1..4)
 // dW0[n][ci][tap] = sum_{b,p} dY[b,p,n] xc[b,ci,p + off(tap)] with xc the centred integer state.  A workgroup takes a band of
 // image rows of one sample: the centred input band (+ halo, zero border) is converted once into LDS, thread = (channel n,
@@ -1261,6 +1376,17 @@ extern "C" int ctdd_unet_attention_bwd(const void* args_, void* stream) {
   const AttnBwdArgs& a = *(const AttnBwdArgs*)args_;
   CTDD_REQUIRE(a.qkv && (a.d_out_f32 || a.d_out_bf16) && (a.d_qkv || a.d_qkv_bf16) && a.C % a.heads == 0, CTDD_EINVAL, "attention bwd: bad arguments");
   const int ch = a.C / a.heads;
+  {
+    const int Tp = (a.T + 3) & ~3;
+    const size_t lds4 = (size_t)(4 * ch * Tp + 3 * a.T * ch + 3 * a.T * Tp) * sizeof(float);
+    static const bool old_attn = [] { const char* e = getenv("CTDD_ATTN_SMALL_OLD"); return e && e[0] == '1'; }();    // (A/B)
+    if (!old_attn && ch % 4 == 0 && a.C % 4 == 0 && lds4 <= 160 * 1024) {
+      static bool done4[16] = {};
+      ensure_lds_ceiling((const void*)k_attn_small_bwd_t4, done4);
+      hipLaunchKernelGGL(k_attn_small_bwd_t4, dim3(a.B * a.heads), dim3(256), lds4, (hipStream_t)stream, a);
+      return finish_launch("k_attn_small_bwd_t4");
+    }
+  }
   const size_t lds = (size_t)(4 * a.T * ch + 2 * a.T * a.T) * sizeof(float);
   CTDD_REQUIRE(lds <= 160 * 1024, CTDD_ERANGE, "attention bwd tile too large (T=%d)", a.T);
   static bool done[16] = {};

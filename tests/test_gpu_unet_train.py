@@ -209,11 +209,12 @@ def test_dropout_mask_is_shared_by_forward_and_backward():
     torch.testing.assert_close(sums[..., 0], want, rtol=1e-5, atol=1e-4)
 
 
-def test_attention_backward():
+@pytest.mark.parametrize("B,T,Cc,heads", [(3, 49, 64, 4), (2, 49, 192, 8), (2, 50, 48, 2), (2, 16, 192, 1)])
+def test_attention_backward(B, T, Cc, heads):
+    """ctdd_unet_attention_bwd (k_attn_small_bwd_t4 where its tables fit the LDS, the thread-per-score kernel otherwise) against autograd
+    through the reference's attention; token counts off the 4 x 4 tile size included."""
     from ctdd import unet_train as ut
-    from lib.networks.unet import SelfAttention
     lib = ut.lib()
-    B, T, Cc, heads = 3, 49, 64, 4
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn((B, T, 3 * Cc), generator=g, device="cuda")
     do = torch.randn((B, T, Cc), generator=g, device="cuda")
