@@ -401,7 +401,9 @@ __device__ inline void hk_mask_tile(f32x16& s, int Tq, int Tk, int i, bool qok, 
 template <int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void k_hollow_attention_mfma(const HollowAttnArgs a) {
   constexpr int KS = HD / 16;                       // k-steps of the score product
-  constexpr int KLD = HD + 8, VLD = 32 + 8;         // LDS row lengths (bf16 elements): 16-byte padded
+  constexpr int KLD = HD + 8, VLD = 32 + 4;         // LDS row lengths (bf16 elements): K rows 16-byte padded; V^T rows of 72 bytes, so that
+                                                    // the 8-byte fragment reads of 32 lanes (a row each) fall on 32 distinct bank pairs (80-byte
+                                                    // rows: lanes 16 apart collided -- 54 % of this kernel's LDS cycles were conflicts)
   constexpr int NT = SPLIT ? 2 : 1;                 // terms per operand: hi (+ lo)
   __shared__ __attribute__((aligned(16))) unsigned short Ksm[NT][32 * KLD];     // [key][dim]
   __shared__ __attribute__((aligned(16))) unsigned short Vsm[NT][32 * VLD];     // [dim][key] (dims >= HD: zero rows)

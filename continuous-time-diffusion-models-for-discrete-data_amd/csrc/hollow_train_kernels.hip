@@ -588,7 +588,9 @@ __device__ inline unsigned mask_bits_kv(int Tq, int j, bool kok, int ib) {
   }
   return m;
 }
-constexpr int RLD16 = 8, TLD = 40;                  // row-major rows: HD + 8 bf16; transposed rows: 32 + 8
+constexpr int RLD16 = 8, TLD = 36;                  // row-major rows: HD + 8 bf16; transposed rows: 32 + 4 -- 72-byte rows put the 8-byte
+                                                    // fragment reads of 32 lanes (one row each) on 32 distinct bank pairs; with 80-byte
+                                                    // rows lanes 16 apart shared theirs (half of these kernels' LDS cycles were conflicts)
 
 // Staging of a chunk of 32 rows of TWO fp32 matrices [row][HD] as bf16, split in a fetch (global -> registers, issued a chunk
 // ahead so that the loads fly under the previous chunk's products) and a store (registers -> LDS: row-major R and / or
