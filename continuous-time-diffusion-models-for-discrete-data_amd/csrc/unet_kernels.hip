@@ -2158,7 +2158,8 @@ __global__ __launch_bounds__(256) void k_attn_small_t4(const AttnArgs a) {
 
 // ------------------------------------------------------------------ logistic head (models.py:249-283)
 // mu = tanh(loc + x0), logits[s] = log(sigmoid(r) - sigmoid(l)) via log_minus_exp, straight into (B,D,S)
-struct LogisticArgs { const float* net; const float* x0; int B, C, HW, S, fix; float* out; int fast; };
+struct LogisticArgs { const float* net; const float* x0; int B, C, HW, S, fix; float* out; int fast;
+                      unsigned short* out_bf16; };      // (fast mode, S % 4 == 0) the logits as bf16 instead: what the bf16 step kernel reads
 __device__ inline float logsigmoidf(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 // hardware exp2 / log2 forms for the bf16 engine mode (~1e-6 relative; the mode's logits carry ~1e-2 already)
 __device__ inline float logsigmoid_fast(float x) { return fminf(x, 0.0f) - __logf(1.0f + __expf(-fabsf(x))); }
@@ -2167,13 +2168,36 @@ __device__ inline float logsigmoid_fast(float x) { return fminf(x, 0.0f) - __log
 __global__ __launch_bounds__(256) void k_logistic_head(const LogisticArgs a) {
   // net: NHWC [B][HW][2C] (loc channels 0..C-1, log_scale C..2C-1); x0: (B,C,HW) centred input
   const int lane = threadIdx.x & 63;
-  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // b*C*HW + c*HW + p
-  if (d >= (int64_t)a.B * a.C * a.HW) return;
+  // (a wave walks rows with the grid's stride: one row per wave and launch -- 24 576 workgroups of a few hundred instructions at
+  //  CIFAR batch 32 -- spent its time in workgroup dispatch: 60 us for 50 MB)
+  const int64_t nrows = (int64_t)a.B * a.C * a.HW;
+  for (int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); d < nrows; d += (int64_t)gridDim.x * 4) {
   const int p = (int)(d % a.HW), c = (int)((d / a.HW) % a.C), b = (int)(d / ((int64_t)a.HW * a.C));
   const float* nr = a.net + ((size_t)b * a.HW + p) * 2 * a.C;
   const float mu = tanhf(nr[c] + a.x0[((size_t)b * a.C + c) * a.HW + p]);
   const float inv_scale = expf(-(nr[a.C + c] - 2.0f));
   const float bw = 2.0f / (float)a.S, stepc = (2.0f - bw) / (float)(a.S - 1);
+  if (a.out_bf16) {
+    // bf16 logits (the sampler loops of the bf16 engine): a lane computes four consecutive bins and stores them as 8 bytes
+    unsigned short* ob = a.out_bf16 + (size_t)d * a.S;
+    for (int s0 = 4 * lane; s0 < a.S; s0 += 256) {
+      float v4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float centre = -1.0f + bw * 0.5f + (float)(s0 + e) * stepc;
+        const float l = (centre - bw * 0.5f - mu) * inv_scale, r = (centre + bw * 0.5f - mu) * inv_scale;
+        const float cl = logsigmoid_fast(l), cr = logsigmoid_fast(r);
+        float v = cr + __logf(1.0f - __expf(cl - cr) + 1e-6f);
+        if (a.fix) {
+          const float a2 = -l + cl, b2 = -r + cr;
+          v = fminf(v, a2 + __logf(1.0f - __expf(b2 - a2) + 1e-6f));
+        }
+        v4[e] = v;
+      }
+      *(uint2*)(ob + s0) = make_uint2(pack2_bf16(v4[0], v4[1]), pack2_bf16(v4[2], v4[3]));
+    }
+    continue;
+  }
   float* out = a.out + (size_t)d * a.S;
   for (int s = lane; s < a.S; s += 64) {
     const float centre = -1.0f + bw * 0.5f + (float)s * stepc;            // torch.linspace
@@ -2195,6 +2219,7 @@ __global__ __launch_bounds__(256) void k_logistic_head(const LogisticArgs a) {
       }
     }
     out[s] = v;
+  }
   }
 }
 
@@ -2558,6 +2583,9 @@ extern "C" int ctdd_unet_attention(const void* args_, void* stream) {
 extern "C" int ctdd_unet_logistic_head(const void* args_, void* stream) {
   const LogisticArgs& a = *(const LogisticArgs*)args_;
   const int64_t rows = (int64_t)a.B * a.C * a.HW;
-  hipLaunchKernelGGL(k_logistic_head, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  CTDD_REQUIRE(a.out || a.out_bf16, CTDD_EINVAL, "logistic head: no output");
+  CTDD_REQUIRE(!a.out_bf16 || (a.fast && a.S % 4 == 0), CTDD_EINVAL, "logistic head: bf16 logits are the fast mode's, S %% 4 == 0");
+  const int64_t wgs = (rows + 3) / 4;
+  hipLaunchKernelGGL(k_logistic_head, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, (hipStream_t)stream, a);
   return finish_launch("k_logistic_head");
 }

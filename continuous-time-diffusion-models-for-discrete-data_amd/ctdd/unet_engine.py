@@ -56,7 +56,7 @@ class _AttnArgs(C.Structure):
 
 
 class _LogisticArgs(C.Structure):
-    _fields_ = [("net", _P), ("x0", _P), ("B", _I), ("C", _I), ("HW", _I), ("S", _I), ("fix", _I), ("out", _P), ("fast", _I)]
+    _fields_ = [("net", _P), ("x0", _P), ("B", _I), ("C", _I), ("HW", _I), ("S", _I), ("fix", _I), ("out", _P), ("fast", _I), ("out_bf16", _P)]
 
 
 _sigs_done = False
@@ -571,10 +571,15 @@ class UNetEngine:
             st.net_out = torch.empty((B * H0 * W0, n_out), dtype=torch.float32, device=dev)
             conv([(ao, ao.C, SEG_3x3)], [(oc.weight, 0)],
                  oc.bias.detach().float().contiguous(), n_out, H0, W0, H0, W0, None, out_f32_tensor=st.net_out, bias_params=[oc.bias])
-            st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=torch.float32, device=dev)
+            ldt = torch.bfloat16 if (logits_bf16 and tc is None and not self.precise and S % 4 == 0) else torch.float32
+            st.logits = logits_out if logits_out is not None else torch.empty((B, D, S), dtype=ldt, device=dev)
+            assert st.logits.dtype == ldt
             la = _LogisticArgs()
-            la.net, la.x0, la.B, la.C, la.HW, la.S, la.fix, la.out = (ptr(st.net_out), ptr(st.x0), B, Cin, H0 * W0, S,
-                                                                     int(bool(m.fix_logistic)), ptr(st.logits))
+            la.net, la.x0, la.B, la.C, la.HW, la.S, la.fix = ptr(st.net_out), ptr(st.x0), B, Cin, H0 * W0, S, int(bool(m.fix_logistic))
+            if ldt == torch.bfloat16:                  # (the sampler loops of the bf16 engine: the head writes what the bf16 step kernel reads)
+                la.out_bf16 = ptr(st.logits)
+            else:
+                la.out = ptr(st.logits)
             la.fast = 0 if self.precise else 1
             keep.append(la)
             if tc is None:                             # (training: the head runs as differentiable device ops on net_out)
@@ -688,13 +693,13 @@ class UNetEngine:
         return out
 
     def __call__(self, x, times, logits_bf16=False, uniform_time=False, slot=None, time_row=None):
-        """logits_bf16: write the (B, D, S) logits in bf16 (bf16 engine with the `logits` head; ignored otherwise).
+        """logits_bf16: write the (B, D, S) logits in bf16 (bf16 engine: the output convolution's epilogue, or the logistic head).
         uniform_time: the caller guarantees that every entry of `times` is the same value (the sampler loops): the time path
         runs once, as one launch, for times[0].
         slot: the caller drives several INDEPENDENT sub-batches itself, each on its own stream (TauL's pipelined loop): plan
         `slot` has buffers of its own and replays on the caller's current stream, with no sub-batch split in here."""
         B = x.shape[0]
-        lb = bool(logits_bf16) and not self.precise and self.cfg.model.model_output == "logits"
+        lb = bool(logits_bf16) and not self.precise and (self.cfg.model.model_output == "logits" or self.net.S % 4 == 0)
         ut = "row" if time_row is not None else bool(uniform_time)          # (time_row: the row of time_table() for this call's time)
         ver = self._weights_version()
         if ver != self._wver:                     # weights changed (optimizer step, EMA swap): re-pack

@@ -88,7 +88,9 @@ typedef struct { const float* qkv; int B, T, C, heads; void* out_hi; float* out_
 int ctdd_unet_attention(const void* attn_args, void* stream);              /* unet.py:176-200 */
 
 typedef struct { const float* net; const float* x0; int B, C, HW, S, fix; float* out;
-                 int fast;   /* 1: hardware exp2/log2 forms (bf16 engine mode) */ } ctdd_logistic_args;
+                 int fast;   /* 1: hardware exp2/log2 forms (bf16 engine mode) */
+                 void* out_bf16;   /* or null; fast mode, S % 4 == 0: the (B, D, S) logits in bf16 instead of `out` (the sampler
+                                    * loops of the bf16 engine: half the bytes of the head's write and the step's read) */ } ctdd_logistic_args;
 int ctdd_unet_logistic_head(const void* logistic_args, void* stream);      /* models.py:249-283 */
 
 #ifdef __cplusplus
